@@ -1,0 +1,312 @@
+"""Generate the golden vectors under tests/golden/ from the reference's own modules.
+
+Run in the build container only (``python tests/golden/make_golden.py``): it imports
+``/root/reference`` (read-only), which does not exist on the GPU box.  The .npz files it
+writes are committed; tests read only those.
+
+What the reference can and cannot provide:
+  * importable with torch alone: classifier_models.{preact_resnet,resnet}, utils.dct,
+    defenses.frequency_based.model, networks.models (behind an empty ``torchvision`` stub: its
+    one use is the dead ``NetC_CelebA1``);
+  * NOT importable: train_generator.py (torchvision/kornia/vit_pytorch/tensorboard missing), so
+    the step trace below drives the reference *modules* with ``torch.optim.SGD`` in the order
+    of train_generator.py:170-255, with the Gaussian blur restated (torchvision is absent) and
+    ``--post_transform_option no_use`` (kornia is absent).
+
+Parameters are never stored (11 M floats): each fixture records the ``torch.manual_seed`` used
+before construction plus (sum, L2) checksums, and the tests rebuild identical parameters by
+constructing combat_amd's mirror modules under the same seed.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+
+from classifier_models.preact_resnet import PreActResNet18  # noqa: E402
+from classifier_models.resnet import ResNet18  # noqa: E402
+from defenses.frequency_based.model import FrequencyModel  # noqa: E402
+from networks.models import UnetGenerator  # noqa: E402
+from utils import dct as ref_dct  # noqa: E402
+
+N_SAMPLE = 64  # sampled entries kept per parameter gradient
+
+
+def rng(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def synth_images(b, hw, seed):
+    """ToTensor + Normalize(0.5, 0.5) of uniform uint8 pixels."""
+    u8 = torch.randint(0, 256, (b, 3, hw, hw), generator=rng(seed), dtype=torch.uint8)
+    return (u8.float() / 255 - 0.5) / 0.5
+
+
+def sample_idx(numel, seed):
+    g = np.random.default_rng(seed)
+    return g.integers(0, numel, size=min(N_SAMPLE, numel)).astype(np.int64)
+
+
+def summarize(named, out, prefix, seed=7):
+    """Per-tensor (sum, l2) + sampled entries; enough to pin 11 M-element gradients."""
+    for i, (k, v) in enumerate(named):
+        v = v.detach().double().flatten()
+        idx = sample_idx(v.numel(), seed + i)
+        out["%s/%s/sum" % (prefix, k)] = np.float64(v.sum())
+        out["%s/%s/l2" % (prefix, k)] = np.float64(v.norm())
+        out["%s/%s/idx" % (prefix, k)] = idx
+        out["%s/%s/val" % (prefix, k)] = v[idx].numpy()
+
+
+def save(name, out):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.1f KB, %d arrays)" % (path, os.path.getsize(path) / 1024, len(out)))
+
+
+class Opt:
+    pass
+
+
+def golden_dct():
+    out = {}
+    for n in (32, 64):
+        x = torch.rand(2, 3, n, n, generator=rng(100 + n)) * 255
+        out["x%d" % n] = x.numpy()
+        out["dct%d" % n] = ref_dct.dct_2d(x).numpy()
+        out["idct%d" % n] = ref_dct.idct_2d(x).numpy()
+        u8 = torch.randint(0, 256, (2, 3, n, n), generator=rng(200 + n), dtype=torch.uint8)
+        out["u8_%d" % n] = u8.numpy()
+        out["dct_u8_%d" % n] = ref_dct.dct_2d(u8).numpy()  # train_generator.py:245 feeds .byte()
+    # low_freq (train_generator.py:47-55) with its gradient
+    sys.modules.pop("config", None)
+    for n, ratio in ((32, 0.65), (64, 0.65)):
+        x = (torch.rand(2, 3, n, n, generator=rng(300 + n)) * 2 - 1).requires_grad_(True)
+        mask = torch.zeros_like(x)
+        mask[:, :, : int(n * ratio), : int(n * ratio)] = 1
+        x_dct = ref_dct.dct_2d((x + 1) / 2 * 255)
+        x_dct = x_dct * mask
+        y = (ref_dct.idct_2d(x_dct) / 255 * 2) - 1
+        g = torch.randn(y.shape, generator=rng(400 + n))
+        (gx,) = torch.autograd.grad(y, x, g)
+        out["lf_x%d" % n] = x.detach().numpy()
+        out["lf_y%d" % n] = y.detach().numpy()
+        out["lf_g%d" % n] = g.numpy()
+        out["lf_gx%d" % n] = gx.numpy()
+    save("dct.npz", out)
+
+
+def golden_unet():
+    out = {}
+    torch.manual_seed(0)
+    net = UnetGenerator(Opt())
+    out["seed"] = np.int64(0)
+    summarize(net.state_dict().items(), out, "param")
+    for tag, b, hw in (("b4", 4, 32), ("b1", 1, 32), ("c64", 2, 64)):
+        x = synth_images(b, hw, 11 + b + hw).requires_grad_(True)
+        y = net(x)
+        g = torch.randn(y.shape, generator=rng(12 + b))
+        grads = torch.autograd.grad(y, [x] + list(net.parameters()), g)
+        out["%s/x" % tag] = x.detach().numpy()
+        out["%s/y" % tag] = y.detach().numpy()
+        out["%s/g" % tag] = g.numpy()
+        out["%s/gx" % tag] = grads[0].numpy()
+        summarize(zip([k for k, _ in net.named_parameters()], grads[1:]), out, "%s/gp" % tag)
+    out["b0/shape"] = np.array(net(torch.zeros(0, 3, 32, 32)).shape)
+    net.train()
+    x = synth_images(2, 32, 5)
+    out["train_equals_eval"] = np.bool_(torch.equal(net(x), net.eval()(x)))
+    save("unet.npz", out)
+
+
+def _classifier_case(net, out, tag, x, targets, train):
+    net.train(train)
+    x = x.clone().requires_grad_(True)
+    logits = net(x)
+    loss = F.cross_entropy(logits, targets)
+    grads = torch.autograd.grad(loss, [x] + list(net.parameters()))
+    out["%s/x" % tag] = x.detach().numpy()
+    out["%s/t" % tag] = targets.numpy()
+    out["%s/logits" % tag] = logits.detach().numpy()
+    out["%s/loss" % tag] = np.float64(loss)
+    out["%s/gx" % tag] = grads[0].numpy()
+    summarize(zip([k for k, _ in net.named_parameters()], grads[1:]), out, "%s/gp" % tag)
+    if train:
+        for k, v in net.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                out["%s/buf/%s" % (tag, k)] = v.numpy().copy()
+
+
+def golden_preact():
+    out = {}
+    torch.manual_seed(0)
+    net = PreActResNet18()
+    out["seed"] = np.int64(0)
+    summarize(net.state_dict().items(), out, "param")
+    x = synth_images(4, 32, 21)
+    t = torch.randint(0, 10, (4,), generator=rng(22))
+    _classifier_case(net, out, "eval0", x, t, False)   # fresh running stats (0 / 1)
+    _classifier_case(net, out, "train", x, t, True)    # batch stats, updates running stats
+    x2 = synth_images(4, 32, 23)
+    _classifier_case(net, out, "eval1", x2, t, False)  # uses the updated running stats
+    save("preact.npz", out)
+
+
+def golden_resnet():
+    out = {}
+    torch.manual_seed(0)
+    net = ResNet18(num_classes=8, input_size=64)
+    out["seed"] = np.int64(0)
+    summarize(net.state_dict().items(), out, "param")
+    x = synth_images(2, 64, 31)
+    t = torch.randint(0, 8, (2,), generator=rng(32))
+    _classifier_case(net, out, "train", x, t, True)
+    _classifier_case(net, out, "eval1", synth_images(2, 64, 33), t, False)
+    save("resnet.npz", out)
+
+
+def golden_freq():
+    out = {}
+    torch.manual_seed(0)
+    net = FrequencyModel(num_classes=2, n_input=3, input_size=32).eval()
+    with torch.no_grad():  # give the BN buffers non-trivial values
+        for i in range(1, 7):
+            bn = getattr(net, "bn%d" % i)
+            bn.running_mean.normal_(0, 0.3, generator=rng(40 + i))
+            bn.running_var.uniform_(0.5, 1.5, generator=rng(50 + i))
+    out["seed"] = np.int64(0)
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            out["buf/" + k] = v.numpy().copy()
+    summarize(net.state_dict().items(), out, "param")
+    img = synth_images(4, 32, 41)
+    u8 = ((img + 1) / 2 * 255).byte()
+    inp = ref_dct.dct_2d(u8)
+    with torch.no_grad():
+        logits = net(inp)
+    out["img"] = img.numpy()
+    out["dct_in"] = inp.numpy()
+    out["logits"] = logits.numpy()
+    ck = os.path.join(REF, "defenses/frequency_based/checkpoints/cifar10/cifar10_original_detector.pth.tar")
+    if os.path.exists(ck):
+        sd = torch.load(ck, map_location="cpu", weights_only=True)["netC"]
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            out["shipped/logits"] = net.eval()(inp).numpy()
+    save("freq.npz", out)
+
+
+def _blur(x, sigma):
+    """torchvision 0.11.2 GaussianBlur(3, sigma) restated (absent library; parity unpinned)."""
+    xs = torch.linspace(-1.0, 1.0, steps=3)
+    k1 = torch.exp(-0.5 * (xs / sigma) ** 2)
+    k1 = k1 / k1.sum()
+    w = torch.outer(k1, k1)[None, None].expand(x.shape[1], 1, 3, 3)
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, groups=x.shape[1])
+
+
+def _low_freq(x, ratio=0.65):
+    n = x.shape[-1]
+    mask = torch.zeros_like(x)
+    mask[:, :, : int(n * ratio), : int(n * ratio)] = 1
+    d = ref_dct.dct_2d((x + 1) / 2 * 255) * mask
+    return ref_dct.idct_2d(d) / 255 * 2 - 1
+
+
+def golden_step():
+    """Three alternated steps driven through the reference nn.Modules + torch.optim.SGD in the
+    order of train_generator.py:170-255 (B=16, no augmentation, recorded num_bd / sigma)."""
+    out = {}
+    b, steps = 16, 3
+    torch.manual_seed(0)
+    netc = PreActResNet18()
+    torch.manual_seed(1)
+    clean = PreActResNet18().eval()
+    torch.manual_seed(2)
+    netg = UnetGenerator(Opt())
+    torch.manual_seed(3)
+    netf = FrequencyModel(num_classes=2, n_input=3, input_size=32).eval()
+    out["seeds"] = np.array([0, 1, 2, 3])
+    opt_c = torch.optim.SGD(netc.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    opt_g = torch.optim.SGD(netg.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    num_bds = [2, 0, 3]
+    sig_c = [0.35, 0.8, 0.55]
+    sig_g = [0.9, 0.2, 0.65]
+    out["num_bd"], out["sigma_c"], out["sigma_g"] = np.array(num_bds), np.array(sig_c), np.array(sig_g)
+    trace = {k: [] for k in ("loss_c", "loss_ce", "loss_l2", "loss_grad_l2", "clean_model_loss", "clean_correct",
+                             "bd_correct", "f_correct", "clean_model_correct", "clean_model_bd_ba",
+                             "clean_model_bd_asr", "gnorm_c", "gnorm_g")}
+    ce = torch.nn.CrossEntropyLoss()
+    for s in range(steps):
+        inputs = synth_images(b, 32, 1234 + s)
+        targets = torch.randint(0, 10, (b,), generator=rng(4321 + s))
+        targets[: 4] = 0  # make sure the target class is present
+        out["step%d/inputs" % s], out["step%d/targets" % s] = inputs.numpy(), targets.numpy()
+        bd_targets = torch.zeros_like(targets)
+        netg.eval(); clean.eval(); netc.train(); opt_c.zero_grad()
+        trg = (targets == bd_targets).nonzero()[:, 0]
+        ntrg = (targets != bd_targets).nonzero()[:, 0]
+        nb = num_bds[s]
+        chg = inputs[trg[:nb]]
+        noise = netg(chg)
+        if nb:
+            noise = _low_freq(noise)
+        ibd = torch.clamp(chg + noise * 0.08, -1, 1)
+        if nb:
+            ibd = _blur(ibd, sig_c[s])
+        tot_in = torch.cat([ibd, inputs[trg[nb:]], inputs[ntrg]], 0)
+        tot_t = torch.cat([bd_targets[trg[:nb]], targets[trg[nb:]], targets[ntrg]], 0)
+        loss_c = ce(netc(tot_in), tot_t)
+        loss_c.backward()
+        trace["gnorm_c"].append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in netc.parameters()))))
+        opt_c.step()
+        clean_preds = clean(inputs)
+        netc.eval(); netg.train(); opt_g.zero_grad()
+        noise = _low_freq(netg(inputs))
+        ibd = _blur(torch.clamp(inputs + noise * 0.08, -1, 1), sig_g[s])
+        pred_clean = netc(inputs)
+        pred_bd = netc(ibd)
+        loss_ce = ce(pred_bd, bd_targets)
+        loss_l2 = F.mse_loss(ibd, inputs)
+        e, eb = F.pad(inputs, (1, 1, 2, 1)), F.pad(ibd, (1, 1, 2, 1))
+        loss_grad_l2 = F.mse_loss(e[:, :, 1:] - e[:, :, :-1], eb[:, :, 1:] - eb[:, :, :-1]) + \
+            F.mse_loss(e[:, :, :, 1:] - e[:, :, :, :-1], eb[:, :, :, 1:] - eb[:, :, :, :-1])
+        pred_f = netf(ref_dct.dct_2d(((ibd + 1) / 2 * 255).byte()))
+        cm_preds = clean(ibd)
+        cm_loss = ce(cm_preds, targets)
+        loss = loss_ce + 0.02 * loss_l2 + 0.8 * cm_loss
+        loss.backward()
+        trace["gnorm_g"].append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in netg.parameters()))))
+        opt_g.step()
+        for k, v in (("loss_c", loss_c), ("loss_ce", loss_ce), ("loss_l2", loss_l2), ("loss_grad_l2", loss_grad_l2),
+                     ("clean_model_loss", cm_loss)):
+            trace[k].append(float(v))
+        trace["clean_correct"].append(int((pred_clean.argmax(1) == targets).sum()))
+        trace["bd_correct"].append(int((pred_bd.argmax(1) == bd_targets).sum()))
+        trace["f_correct"].append(int((pred_f.argmax(1) == 1).sum()))
+        trace["clean_model_correct"].append(int((clean_preds.argmax(1) == targets).sum()))
+        trace["clean_model_bd_ba"].append(int((cm_preds.argmax(1) == targets).sum()))
+        trace["clean_model_bd_asr"].append(int((cm_preds.argmax(1) == bd_targets).sum()))
+        out["step%d/inputs_bd" % s] = ibd.detach().numpy()
+    for k, v in trace.items():
+        out["trace/" + k] = np.array(v, dtype=np.float64)
+    summarize(netc.state_dict().items(), out, "final/netc")
+    summarize(netg.state_dict().items(), out, "final/netg")
+    save("step.npz", out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    golden_dct()
+    golden_unet()
+    golden_preact()
+    golden_resnet()
+    golden_freq()
+    golden_step()
