@@ -1,0 +1,121 @@
+"""ctypes binding of libcombat_hip.so (the C ABI declared in include/combat_hip.h).
+
+The product path has no fallback: if the shared library is missing or does not export a symbol
+the header declares, importing this module raises.  Build it with ``python -m combat_amd.build``
+(hipcc cross-compiles gfx950 without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcombat_hip.so")
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvArgs(C.Structure):
+    """struct combat_conv_args"""
+
+    _fields_ = [
+        ("N", c_i32), ("H", c_i32), ("W", c_i32), ("C", c_i32),
+        ("P", c_i32), ("Q", c_i32), ("K", c_i32),
+        ("R", c_i32), ("S", c_i32), ("stride", c_i32), ("pad", c_i32),
+        ("mode", c_i32),
+        ("src", c_vp), ("wpack", c_vp), ("kpad", c_i32), ("rows_pad", c_i32), ("dst", c_vp),
+        ("pro_scale", c_vp), ("pro_shift", c_vp), ("pro_group_stride", c_i32), ("pro_act", c_i32),
+        ("pro_slope", c_f32),
+        ("bias", c_vp), ("add_pre", c_vp), ("mask_x", c_vp), ("mask_scale", c_vp), ("mask_shift", c_vp),
+        ("mask_group_stride", c_i32), ("mask_slope", c_f32), ("mask_mul_scale", c_i32),
+        ("add_post", c_vp), ("tanh_out", c_i32),
+        ("stats_kind", c_i32), ("stats", c_vp), ("xh_scale", c_vp), ("xh_shift", c_vp),
+        ("tile", c_i32),
+    ]
+
+
+class WgradArgs(C.Structure):
+    """struct combat_wgrad_args"""
+
+    _fields_ = [
+        ("N", c_i32), ("H", c_i32), ("W", c_i32), ("C", c_i32),
+        ("P", c_i32), ("Q", c_i32), ("K", c_i32),
+        ("R", c_i32), ("S", c_i32), ("stride", c_i32), ("pad", c_i32),
+        ("src", c_vp), ("dy", c_vp), ("dw", c_vp), ("k_real", c_i32), ("c_real", c_i32),
+        ("pro_scale", c_vp), ("pro_shift", c_vp), ("pro_group_stride", c_i32), ("pro_act", c_i32),
+        ("pro_slope", c_f32), ("split", c_i32),
+    ]
+
+
+# name -> (restype, argtypes); one entry per function declared in include/combat_hip.h
+SIGNATURES = {
+    "combat_version": (C.c_char_p, []),
+    "combat_abi_version": (C.c_int, []),
+    "combat_conv_gemm": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
+    "combat_conv_pick_tile": (C.c_int, [C.POINTER(ConvArgs)]),
+    "combat_conv_stats_granule": (C.c_int, [C.c_int]),
+    "combat_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
+    "combat_pack_weights": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32,
+                                      c_i32, c_vp]),
+    "combat_norm_finalize": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp]),
+    "combat_norm_scratch_bytes": (c_i64, [c_i32, c_i32]),
+    "combat_bn_eval_fold": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp]),
+    "combat_group_stats": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_norm_bwd_finalize": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "combat_norm_bwd_apply": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "combat_group_stats_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "combat_unet_up_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_unet_up_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_trigger_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "combat_trigger_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
+    "combat_augment_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "combat_augment_bwd": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "combat_head_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                  c_vp, c_vp, c_vp]),
+    "combat_head_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                  c_vp]),
+    "combat_sgd_nesterov": (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "combat_image_to_c8": (C.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "combat_nhwc_to_nchw_f32": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_nchw_to_nhwc_bf16": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "combat_maxpool2": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_elu_affine": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "combat_dct_u8": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "combat_linear_nhwc": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
+}
+
+TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x16, TILE_64x128 = 1, 2, 3, 4, 5
+
+
+class CombatHipError(RuntimeError):
+    pass
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    if not os.path.exists(path):
+        raise ImportError(
+            "combat_amd: %s not found -- the HIP library is required (no CPU fallback exists); "
+            "build it with `python -m combat_amd.build`" % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError("combat_amd: %s does not export %s" % (path, name)) from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()
+
+
+def check(status: int, what: str, detail: str = "") -> None:
+    """Map a C status code to a Python exception naming the kernel and the shape."""
+    if status == 0:
+        return
+    kind = {-1: "invalid shape/argument", -2: "HIP launch failed"}.get(status, "status %d" % status)
+    raise CombatHipError("%s: %s %s" % (what, kind, detail))

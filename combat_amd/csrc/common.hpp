@@ -1,0 +1,65 @@
+// Shared device helpers for the combat_hip kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "combat_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+#define CB_LAUNCH_CHECK()                                  \
+    do {                                                   \
+        if (hipGetLastError() != hipSuccess) return COMBAT_ELAUNCH; \
+    } while (0)
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
+
+// fp32 -> bf16 (RNE; NaN stays NaN): a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
+    v[0] = bf16_bits_to_f32(u.x & 0xffffu);
+    v[1] = bf16_bits_to_f32(u.x >> 16);
+    v[2] = bf16_bits_to_f32(u.y & 0xffffu);
+    v[3] = bf16_bits_to_f32(u.y >> 16);
+    v[4] = bf16_bits_to_f32(u.z & 0xffffu);
+    v[5] = bf16_bits_to_f32(u.z >> 16);
+    v[6] = bf16_bits_to_f32(u.w & 0xffffu);
+    v[7] = bf16_bits_to_f32(u.w >> 16);
+}
+
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    uint4 u;
+    u.x = pack_bf16x2(v[0], v[1]);
+    u.y = pack_bf16x2(v[2], v[3]);
+    u.z = pack_bf16x2(v[4], v[5]);
+    u.w = pack_bf16x2(v[6], v[7]);
+    return u;
+}
+
+__device__ __forceinline__ void load8f(const float *p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4 *>(p);
+    const float4 b = *reinterpret_cast<const float4 *>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+__device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}

@@ -1,0 +1,284 @@
+// Convolution weight gradient on bf16 MFMA (gfx950):
+//
+//   dW[n][tap][c] += sum_{m in pixel range} dy[m][n] * prologue(src[pix(m,tap)][c])
+//
+// GEMM view: rows = dy channels (n), cols = src channels (c), reduction = pixels.  Both operands
+// live in HBM pixel-major (NHWC), i.e. with the reduction index as the SLOW dimension, so the
+// 64-pixel tiles are staged into LDS exactly as loaded ([pixel][channel] rows) and the MFMA
+// fragments are fetched with ds_read_b64_tr_b16, whose 4x16 transposing read hands each lane
+// 4 consecutive pixels of one channel -- no shuffles, no transposed copy.
+// One workgroup = one (n-tile, c-tile, tap, pixel range); partial sums over pixel ranges are
+// combined with fp32 atomics on the [K][taps][c] gradient (contiguous 256-B runs per wave).
+//
+// Replaces the weight-gradient half of autograd's conv backward for the lines listed in
+// conv_gemm.hip; the prologue recomputes the normalised/activated conv input from the saved
+// pre-normalisation tensor, as the forward kernel does.
+#include "common.hpp"
+
+namespace {
+
+struct WgradParams {
+    combat_wgrad_args a;
+    int M, PQ, ntaps, tiles_k, tiles_c, split, pix_per_split;
+};
+
+template <int BMC, int BNC>
+struct WCfg {
+    static constexpr int WGK = (BNC == 16) ? 4 : (BMC == 16 ? 1 : 2);
+    static constexpr int WGC = 4 / WGK;
+    static constexpr int WK = BMC / WGK;
+    static constexpr int WC = BNC / WGC;
+    static constexpr int FK = WK / 16;
+    static constexpr int FC = WC / 16;
+    static constexpr int SK = (BMC + 16) * 2;  // LDS row strides in bytes
+    static constexpr int SC = (BNC + 16) * 2;
+    static constexpr int CHK = BMC / 8;
+    static constexpr int CHC = BNC / 8;
+    static constexpr int ITK = (64 * CHK + 255) / 256;
+    static constexpr int ITC = (64 * CHC + 255) / 256;
+    static constexpr int BUF = 64 * (SK + SC);
+    static constexpr int EPS = BNC + 4;
+    static constexpr int EP_BYTES = BMC * EPS * 4;
+    static constexpr int SMEM = (2 * BUF > EP_BYTES) ? 2 * BUF : EP_BYTES;
+};
+
+__device__ __forceinline__ s16x4_t lds_tr16(const unsigned char *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t *)(reinterpret_cast<uintptr_t>(p)));
+}
+
+template <int BMC, int BNC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    using T = WCfg<BMC, BNC>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const combat_wgrad_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wave_k = wid % T::WGK, wave_c = wid / T::WGK;
+
+    int bid = blockIdx.x;
+    const int tile_c = bid % p.tiles_c; bid /= p.tiles_c;
+    const int tile_k = bid % p.tiles_k; bid /= p.tiles_k;
+    const int tap = bid % p.ntaps;
+    const int sp = bid / p.ntaps;
+    const int k0 = tile_k * BMC, c0 = tile_c * BNC;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const int m_begin = sp * p.pix_per_split;
+    int m_end = m_begin + p.pix_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int nkt = (m_end - m_begin + 63) / 64;
+    if (nkt <= 0) return;
+
+    const __bf16 *__restrict__ src = reinterpret_cast<const __bf16 *>(a.src);
+    const __bf16 *__restrict__ dy = reinterpret_cast<const __bf16 *>(a.dy);
+    const int C = a.C, K = a.K, H = a.H, W = a.W;
+    const bool pro_affine = a.pro_scale != nullptr;
+
+    uint4 rk[T::ITK], rc[T::ITC];
+    unsigned vc = 0;
+    int gc[T::ITC];
+
+    auto load_tile = [&](int kt) {
+        const int mt = m_begin + kt * 64;
+#pragma unroll
+        for (int i = 0; i < T::ITK; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / T::CHK, ch = idx % T::CHK;
+            const int m = mt + row, n = k0 + ch * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < 64 * T::CHK && m < m_end && n < K) v = *reinterpret_cast<const uint4 *>(dy + (size_t)m * K + n);
+            rk[i] = v;
+        }
+        vc = 0;
+#pragma unroll
+        for (int i = 0; i < T::ITC; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / T::CHC, ch = idx % T::CHC;
+            const int m = mt + row, c = c0 + ch * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            gc[i] = 0;
+            if (idx < 64 * T::CHC && m < m_end && c < C) {
+                const int img = m / p.PQ, rem = m - img * p.PQ;
+                const int oy = rem / a.Q, ox = rem - oy * a.Q;
+                const int iy = oy * a.stride - a.pad + r, ix = ox * a.stride - a.pad + s;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    v = *reinterpret_cast<const uint4 *>(src + ((size_t)(img * H + iy) * W + ix) * C + c);
+                    vc |= 1u << i;
+                    gc[i] = img * a.pro_group_stride;
+                }
+            }
+            rc[i] = v;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        unsigned char *kl = smem + buf * T::BUF;
+        unsigned char *cl = kl + 64 * T::SK;
+#pragma unroll
+        for (int i = 0; i < T::ITK; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 64 * T::CHK) {
+                const int row = idx / T::CHK, ch = idx % T::CHK;
+                *reinterpret_cast<uint4 *>(kl + row * T::SK + ch * 16) = rk[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < T::ITC; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 64 * T::CHC) {
+                const int row = idx / T::CHC, ch = idx % T::CHC;
+                uint4 val = rc[i];
+                if ((pro_affine || a.pro_act) && ((vc >> i) & 1u)) {
+                    float v[8];
+                    unpack8(val, v);
+                    if (pro_affine) {
+                        float sc[8], sh[8];
+                        load8f(a.pro_scale + gc[i] + c0 + ch * 8, sc);
+                        load8f(a.pro_shift + gc[i] + c0 + ch * 8, sh);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                    }
+                    if (a.pro_act) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.pro_slope;
+                    }
+                    val = pack8(v);
+                }
+                *reinterpret_cast<uint4 *>(cl + row * T::SC + ch * 16) = val;
+            }
+        }
+    };
+
+    f32x4_t acc[T::FK][T::FC];
+#pragma unroll
+    for (int i = 0; i < T::FK; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FC; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int buf) {
+        const unsigned char *kl = smem + buf * T::BUF;
+        const unsigned char *cl = kl + 64 * T::SK;
+        // transposing read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
+        // 4(pixel) x 16(channel) block and receives the 4 pixels of channel (lane & 15)
+        const int q = (lane & 15) >> 2, pp = lane & 3, fq = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int prow = ks * 32 + fq * 8 + q;
+            bf16x8_t fk[T::FK], fc[T::FC];
+#pragma unroll
+            for (int i = 0; i < T::FK; ++i) {
+                const unsigned char *b = kl + prow * T::SK + (wave_k * T::WK + i * 16 + pp * 4) * 2;
+                const s16x4_t lo = lds_tr16(b), hi = lds_tr16(b + 4 * T::SK);
+                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fk[i] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int j = 0; j < T::FC; ++j) {
+                const unsigned char *b = cl + prow * T::SC + (wave_c * T::WC + j * 16 + pp * 4) * 2;
+                const s16x4_t lo = lds_tr16(b), hi = lds_tr16(b + 4 * T::SC);
+                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fc[j] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int i = 0; i < T::FK; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FC; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[i], fc[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile(kt + 1);
+        compute(kt & 1);
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // accumulators (lane: 4 consecutive dy channels of one src channel) -> fp32 LDS image
+    float *ep = reinterpret_cast<float *>(smem);
+    {
+        const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < T::FK; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FC; ++j) {
+                const int col = wave_c * T::WC + j * 16 + fr;
+                const int row = wave_k * T::WK + i * 16 + fq * 4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ep[(row + e) * T::EPS + col] = acc[i][j][e];
+            }
+    }
+    __syncthreads();
+    const int creal = a.c_real;
+    for (int idx = tid; idx < BMC * BNC; idx += 256) {
+        const int row = idx / BNC, col = idx - row * BNC;
+        const int n = k0 + row;
+        int c = c0 + col;
+        if (n >= a.k_real || c >= C) continue;
+        if (creal < C) {  // hi/lo image channels fold onto the real ones
+            if (c >= 2 * creal) continue;
+            if (c >= creal) c -= creal;
+        }
+        atomicAdd(a.dw + ((size_t)n * p.ntaps + tap) * creal + c, ep[row * T::EPS + col]);
+    }
+}
+
+template <int BMC, int BNC>
+int launch(WgradParams p, hipStream_t st) {
+    using T = WCfg<BMC, BNC>;
+    static bool attr_set = false;
+    auto kern = conv_wgrad_kernel<BMC, BNC>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                T::SMEM) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_set = true;
+    }
+    p.tiles_k = (p.a.K + BMC - 1) / BMC;
+    p.tiles_c = (p.a.C + BNC - 1) / BNC;
+    int split = p.a.split;
+    const int ktiles = (p.M + 63) / 64;
+    if (split <= 0) {
+        const int base = p.tiles_k * p.tiles_c * p.ntaps;
+        split = (1024 + base - 1) / base;
+        const int max_split = (ktiles + 3) / 4;  // at least 4 reduction steps per block
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+    }
+    if (split > ktiles) split = ktiles;
+    p.pix_per_split = ((ktiles + split - 1) / split) * 64;
+    p.split = (p.M + p.pix_per_split - 1) / p.pix_per_split;
+    const long blocks = (long)p.tiles_k * p.tiles_c * p.ntaps * p.split;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), T::SMEM, st, p);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+}  // namespace
+
+extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
+    if (!a || !a->src || !a->dy || !a->dw) return COMBAT_EINVAL;
+    if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->P <= 0 || a->Q <= 0) return COMBAT_EINVAL;
+    if (a->C < 8 || (a->C & 7) || a->K < 8 || (a->K & 7)) return COMBAT_EINVAL;
+    if (a->R != a->S || (a->R != 1 && a->R != 3)) return COMBAT_EINVAL;
+    if (a->stride != 1 && a->stride != 2) return COMBAT_EINVAL;
+    if (a->c_real <= 0 || a->c_real > a->C || a->k_real <= 0 || a->k_real > a->K) return COMBAT_EINVAL;
+    if ((a->pro_scale == nullptr) != (a->pro_shift == nullptr)) return COMBAT_EINVAL;
+    WgradParams p;
+    p.a = *a;
+    p.PQ = a->P * a->Q;
+    const long M = (long)a->N * p.PQ;
+    if (M > 0x7fffffffL / 8) return COMBAT_EINVAL;
+    p.M = (int)M;
+    p.ntaps = a->R * a->S;
+    hipStream_t st = as_stream(stream);
+    if (a->C <= 16) return launch<64, 16>(p, st);
+    if (a->K <= 16) return launch<16, 64>(p, st);
+    if (a->C % 128 == 0 && a->K % 128 == 0) return launch<128, 128>(p, st);
+    return launch<64, 64>(p, st);
+}

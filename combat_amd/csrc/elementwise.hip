@@ -1,0 +1,439 @@
+// Data-movement and element-wise kernels around the convolutions: weight packing, image layout
+// changes, the UNet decoder's norm+skip+upsample glue, multi-tensor Nesterov SGD, pooling.
+// All HBM-bound; every global access is a 16-byte (8 x bf16 / 4 x fp32) vector where the layout
+// allows it.
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ weight packing
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, int K, int taps, int creal,
+                                                           int C, int dup, __bf16 *__restrict__ wf, int rows_f,
+                                                           int kpad_f, __bf16 *__restrict__ wd, int rows_d,
+                                                           int kpad_d, int Kc) {
+    const long nf = (long)rows_f * kpad_f;
+    const long nd = wd ? (long)rows_d * kpad_d : 0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nf + nd; t += (long)gridDim.x * blockDim.x) {
+        if (t < nf) {
+            const int n = (int)(t / kpad_f), k = (int)(t - (long)n * kpad_f);
+            const int tap = k / C, c = k - tap * C;
+            float v = 0.f;
+            if (n < K && tap < taps) {
+                int cm = -1;
+                if (c < creal) cm = c;
+                else if (dup && c < 2 * creal) cm = c - creal;
+                if (cm >= 0) v = w[((long)n * taps + tap) * creal + cm];
+            }
+            wf[t] = (__bf16)v;
+        } else {
+            const long u = t - nf;
+            const int c = (int)(u / kpad_d), k = (int)(u - (long)c * kpad_d);
+            const int tap = k / Kc, n = k - tap * Kc;
+            float v = 0.f;
+            if (c < creal && tap < taps && n < K) v = w[((long)n * taps + tap) * creal + c];
+            wd[u] = (__bf16)v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ image layout
+__device__ __forceinline__ uint4 hilo_pixel(float r, float g, float b) {
+    const float hr = round_bf16(r), hg = round_bf16(g), hb = round_bf16(b);
+    uint4 u;
+    u.x = pack_bf16x2(hr, hg);
+    u.y = pack_bf16x2(hb, r - hr);
+    u.z = pack_bf16x2(g - hg, b - hb);
+    u.w = 0;
+    return u;
+}
+
+__global__ __launch_bounds__(256) void image_to_c8_kernel(const float *__restrict__ x, int n, int hw2,
+                                                          uint4 *__restrict__ out) {
+    const long total = (long)n * hw2;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long img = t / hw2, px = t - img * hw2;
+        const float *p = x + img * 3 * hw2 + px;
+        out[t] = hilo_pixel(p[0], p[hw2], p[2 * hw2]);
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const __bf16 *__restrict__ x, int n, int hw2, int C, int c,
+                                                           float *__restrict__ out) {
+    const long total = (long)n * c * hw2;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long img = t / ((long)c * hw2);
+        const long rem = t - img * c * hw2;
+        const int ch = (int)(rem / hw2);
+        const long px = rem - (long)ch * hw2;
+        out[t] = (float)x[(img * hw2 + px) * C + ch];
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ x, int n, int c, int hw2, int C,
+                                                           __bf16 *__restrict__ out) {
+    const long total = (long)n * hw2 * C;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long pix = t / C;
+        const int ch = (int)(t - pix * C);
+        const long img = pix / hw2, px = pix - img * hw2;
+        out[t] = (__bf16)(ch < c ? x[(img * c + ch) * hw2 + px] : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------ column sums
+__global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ x, long rows, int C, int c_out,
+                                                     float *__restrict__ out) {
+    // one block per 8-channel chunk; deterministic tree over the block
+    __shared__ float sh[256][8];
+    const int c = blockIdx.x * 8;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    for (long r = threadIdx.x; r < rows; r += 256) {
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4 *>(x + r * C + c), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[threadIdx.x][e] = s[e];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh[threadIdx.x][e] += sh[threadIdx.x + o][e];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 8 && c + (int)threadIdx.x < c_out) out[c + threadIdx.x] = sh[0][threadIdx.x];
+}
+
+// ------------------------------------------------------------------ max pool / ELU+affine
+__global__ __launch_bounds__(256) void maxpool2_kernel(const __bf16 *__restrict__ x, int n, int h, int w, int C,
+                                                       __bf16 *__restrict__ out) {
+    const int nch = C >> 3, ho = h >> 1, wo = w >> 1;
+    const long total = (long)n * ho * wo * nch;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(t % nch);
+        long p = t / nch;
+        const int ox = (int)(p % wo);
+        p /= wo;
+        const int oy = (int)(p % ho);
+        const long img = p / ho;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4 *>(x + ((img * h + 2 * oy + dy) * w + 2 * ox + dx) * C + ch * 8), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        *reinterpret_cast<uint4 *>(out + ((img * ho + oy) * wo + ox) * C + ch * 8) = pack8(m);
+    }
+}
+
+__global__ __launch_bounds__(256) void elu_affine_kernel(const __bf16 *__restrict__ x, long rows, int C,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, __bf16 *__restrict__ out) {
+    const int nch = C >> 3;
+    const long total = rows * nch;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % nch) * 8;
+        float v[8], sc[8], sh[8];
+        unpack8(*reinterpret_cast<const uint4 *>(x + t * 8), v);
+        load8f(scale + c, sc);
+        load8f(shift + c, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float el = v[e] > 0.f ? v[e] : expm1f(v[e]);
+            v[e] = fmaf(el, sc[e], sh[e]);
+        }
+        *reinterpret_cast<uint4 *>(out + t * 8) = pack8(v);
+    }
+}
+
+// ------------------------------------------------------------------ UNet decoder glue
+// u = y*sy+ty (+ lrelu(s*ss+ts)); out = lrelu(up2x(u)), align_corners=False:
+//   out[2i]   = .25*u[max(i-1,0)] + .75*u[i];   out[2i+1] = .75*u[i] + .25*u[min(i+1,H-1)]
+__device__ __forceinline__ void up_taps(int o, int n, int &i0, int &i1, float &w0, float &w1) {
+    const int i = o >> 1;
+    if (o & 1) {
+        i0 = i;
+        i1 = i + 1 < n ? i + 1 : n - 1;
+        w0 = 0.75f;
+        w1 = 0.25f;
+    } else {
+        i0 = i > 0 ? i - 1 : 0;
+        i1 = i;
+        w0 = 0.25f;
+        w1 = 0.75f;
+    }
+}
+
+struct UpArgs {
+    const __bf16 *y, *s;
+    const float *sy, *ty, *ss, *ts;
+    int N, H, W, C;
+    __bf16 *out;
+};
+
+__device__ __forceinline__ void u_value(const UpArgs &a, long img, int iy, int ix, int c, float (&u)[8]) {
+    const long off = ((img * a.H + iy) * a.W + ix) * a.C + c;
+    float v[8], sc[8], sh[8];
+    unpack8(*reinterpret_cast<const uint4 *>(a.y + off), v);
+    load8f(a.sy + img * a.C + c, sc);
+    load8f(a.ty + img * a.C + c, sh);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) u[e] = fmaf(v[e], sc[e], sh[e]);
+    if (a.s) {
+        unpack8(*reinterpret_cast<const uint4 *>(a.s + off), v);
+        load8f(a.ss + img * a.C + c, sc);
+        load8f(a.ts + img * a.C + c, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float q = fmaf(v[e], sc[e], sh[e]);
+            u[e] += q > 0.f ? q : 0.2f * q;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void unet_up_fwd_kernel(const UpArgs a) {
+    const int nch = a.C >> 3, Ho = 2 * a.H, Wo = 2 * a.W;
+    const long total = (long)a.N * Ho * Wo * nch;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % nch) * 8;
+        long p = t / nch;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const long img = p / Ho;
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        up_taps(oy, a.H, y0, y1, wy0, wy1);
+        up_taps(ox, a.W, x0, x1, wx0, wx1);
+        float u00[8], u01[8], u10[8], u11[8], o[8];
+        u_value(a, img, y0, x0, c, u00);
+        u_value(a, img, y0, x1, c, u01);
+        u_value(a, img, y1, x0, c, u10);
+        u_value(a, img, y1, x1, c, u11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = wy0 * (wx0 * u00[e] + wx1 * u01[e]) + wy1 * (wx0 * u10[e] + wx1 * u11[e]);
+            o[e] = v > 0.f ? v : 0.2f * v;
+        }
+        *reinterpret_cast<uint4 *>(a.out + ((img * Ho + oy) * Wo + ox) * a.C + c) = pack8(o);
+    }
+}
+
+// du[i] = sum over the (<=3 per axis) output rows that read u[i], of weight * d_out*lrelu'(out)
+__global__ __launch_bounds__(256) void unet_up_bwd_kernel(const __bf16 *__restrict__ d_out,
+                                                          const __bf16 *__restrict__ out, int N, int H, int W, int C,
+                                                          __bf16 *__restrict__ du) {
+    const int nch = C >> 3, Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)N * H * W * nch;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % nch) * 8;
+        long p = t / nch;
+        const int ix = (int)(p % W);
+        p /= W;
+        const int iy = (int)(p % H);
+        const long img = p / H;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int oy = 2 * iy - 1; oy <= 2 * iy + 2; ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            int y0, y1;
+            float wy0, wy1;
+            up_taps(oy, H, y0, y1, wy0, wy1);
+            const float wy = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = 2 * ix - 1; ox <= 2 * ix + 2; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                int x0, x1;
+                float wx0, wx1;
+                up_taps(ox, W, x0, x1, wx0, wx1);
+                const float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+                if (wx == 0.f) continue;
+                const long off = ((img * Ho + oy) * Wo + ox) * C + c;
+                float g[8], o[8];
+                unpack8(*reinterpret_cast<const uint4 *>(d_out + off), g);
+                unpack8(*reinterpret_cast<const uint4 *>(out + off), o);
+                const float wgt = wy * wx;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt * (o[e] > 0.f ? 1.f : 0.2f), g[e], acc[e]);
+            }
+        }
+        *reinterpret_cast<uint4 *>(du + ((img * H + iy) * W + ix) * C + c) = pack8(acc);
+    }
+}
+
+// ------------------------------------------------------------------ SGD
+__global__ __launch_bounds__(256) void sgd_kernel(void *const *__restrict__ ptrs, const int64_t *__restrict__ sizes,
+                                                  float lr, float mu, float wd, float gscale, int first) {
+    const int t = blockIdx.y;
+    float *__restrict__ p = reinterpret_cast<float *>(ptrs[3 * t]);
+    const float *__restrict__ g = reinterpret_cast<const float *>(ptrs[3 * t + 1]);
+    float *__restrict__ b = reinterpret_cast<float *>(ptrs[3 * t + 2]);
+    const long n = sizes[t];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float gv = fmaf(wd, pv, g[i] * gscale);
+        const float bv = first ? gv : fmaf(mu, b[i], gv);
+        b[i] = bv;
+        p[i] = pv - lr * fmaf(mu, bv, gv);
+    }
+}
+
+// ------------------------------------------------------------------ fp32 linear on NHWC features
+__global__ __launch_bounds__(256) void linear_nhwc_kernel(const __bf16 *__restrict__ x, int h, int w, int C,
+                                                          const float *__restrict__ Wt, const float *__restrict__ b,
+                                                          int classes, float *__restrict__ logits) {
+    // block per sample; feature index of torch's flatten = (c*h + y)*w + xx
+    __shared__ float red[256];
+    const int img = blockIdx.x;
+    const int in = C * h * w;
+    for (int j = 0; j < classes; ++j) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < in; i += 256) {
+            const int c = i / (h * w), r = i - c * h * w;
+            s = fmaf((float)x[((long)img * h * w + r) * C + c], Wt[(long)j * in + i], s);
+        }
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) logits[(long)img * classes + j] = red[0] + b[j];
+        __syncthreads();
+    }
+}
+
+inline unsigned grid_for(long total, int cap = 4096) {
+    long b = (total + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int combat_pack_weights(const float *w, int32_t K, int32_t taps, int32_t c_real, int32_t C,
+                                   int32_t dup_hilo, void *wf, int32_t rows_pad_f, int32_t kpad_f, void *wd,
+                                   int32_t rows_pad_d, int32_t kpad_d, void *stream) {
+    if (!w || !wf || K <= 0 || taps <= 0 || c_real <= 0 || C < c_real || (C & 7)) return COMBAT_EINVAL;
+    if (rows_pad_f < K || kpad_f < taps * C || (kpad_f & 63)) return COMBAT_EINVAL;
+    const int Kc = (K + 7) & ~7;
+    if (wd && (rows_pad_d < C || kpad_d < taps * Kc || (kpad_d & 63))) return COMBAT_EINVAL;
+    const long total = (long)rows_pad_f * kpad_f + (wd ? (long)rows_pad_d * kpad_d : 0);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, K, taps, c_real,
+                       C, dup_hilo, reinterpret_cast<__bf16 *>(wf), rows_pad_f, kpad_f, reinterpret_cast<__bf16 *>(wd),
+                       rows_pad_d, kpad_d, Kc);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_image_to_c8(const float *x, int32_t n, int32_t hw, void *out_c8, void *stream) {
+    if (!x || !out_c8 || n < 0 || hw <= 0) return COMBAT_EINVAL;
+    if (n == 0) return COMBAT_OK;
+    hipLaunchKernelGGL(image_to_c8_kernel, dim3(grid_for((long)n * hw * hw)), dim3(256), 0, as_stream(stream), x, n,
+                       hw * hw, reinterpret_cast<uint4 *>(out_c8));
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_nhwc_to_nchw_f32(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, int32_t c,
+                                       float *out, void *stream) {
+    if (!x || !out || n < 0 || h <= 0 || w <= 0 || c <= 0 || c > C) return COMBAT_EINVAL;
+    if (n == 0) return COMBAT_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)n * c * h * w)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const __bf16 *>(x), n, h * w, C, c, out);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t C,
+                                        void *out, void *stream) {
+    if (!x || !out || n < 0 || h <= 0 || w <= 0 || c <= 0 || c > C || (C & 7)) return COMBAT_EINVAL;
+    if (n == 0) return COMBAT_OK;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)n * h * w * C)), dim3(256), 0, as_stream(stream), x, n,
+                       c, h * w, C, reinterpret_cast<__bf16 *>(out));
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || c_out <= 0 || c_out > C) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(colsum_kernel, dim3((c_out + 7) / 8), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const __bf16 *>(x), (long)rows, C, c_out, out);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_maxpool2(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, void *out, void *stream) {
+    if (!x || !out || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || (C & 7)) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for((long)n * (h / 2) * (w / 2) * (C / 8))), dim3(256), 0,
+                       as_stream(stream), reinterpret_cast<const __bf16 *>(x), n, h, w, C,
+                       reinterpret_cast<__bf16 *>(out));
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_elu_affine(const void *x, int64_t rows, int32_t C, const float *scale, const float *shift,
+                                 void *out, void *stream) {
+    if (!x || !out || !scale || !shift || rows <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(elu_affine_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const __bf16 *>(x), (long)rows, C, scale, shift,
+                       reinterpret_cast<__bf16 *>(out));
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_unet_up_fwd(const void *y, const float *sy, const float *ty, const void *s, const float *ss,
+                                  const float *ts, int32_t N, int32_t H, int32_t W, int32_t C, void *out,
+                                  void *stream) {
+    if (!y || !sy || !ty || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
+    if (s && (!ss || !ts)) return COMBAT_EINVAL;
+    UpArgs a{reinterpret_cast<const __bf16 *>(y), reinterpret_cast<const __bf16 *>(s), sy, ty, ss, ts, N, H, W, C,
+             reinterpret_cast<__bf16 *>(out)};
+    hipLaunchKernelGGL(unet_up_fwd_kernel, dim3(grid_for((long)N * 4 * H * W * (C / 8), 8192)), dim3(256), 0,
+                       as_stream(stream), a);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N, int32_t H, int32_t W, int32_t C,
+                                  void *du, void *stream) {
+    if (!d_out || !out || !du || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(unet_up_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8), 8192)), dim3(256), 0,
+                       as_stream(stream), reinterpret_cast<const __bf16 *>(d_out), reinterpret_cast<const __bf16 *>(out),
+                       N, H, W, C, reinterpret_cast<__bf16 *>(du));
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_sgd_nesterov(const void *ptrs, const int64_t *sizes, int32_t count, int64_t max_size, float lr,
+                                   float momentum, float weight_decay, float grad_scale, int32_t first_step,
+                                   void *stream) {
+    if (!ptrs || !sizes || count <= 0 || max_size <= 0) return COMBAT_EINVAL;
+    long bx = (max_size + 255) / 256;
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<void *const *>(ptrs), sizes, lr, momentum, weight_decay, grad_scale, first_step);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_linear_nhwc(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, const float *Wt,
+                                  const float *b, int32_t classes, float *logits, void *stream) {
+    if (!x || !Wt || !b || !logits || n <= 0 || h <= 0 || w <= 0 || C <= 0 || classes <= 0) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(linear_nhwc_kernel, dim3(n), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const __bf16 *>(x), h, w, C, Wt, b, classes, logits);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}

@@ -1,0 +1,181 @@
+// Classifier head: avg_pool(4) -> flatten -> Linear -> CrossEntropyLoss, forward and backward.
+// Tiny (B x 512 features), latency-bound; one workgroup per sample, fp32 throughout.
+//
+// Replaces: F.avg_pool2d / nn.AvgPool2d(4), view, nn.Linear (preact_resnet.py:82-83,99-101;
+// resnet.py:93-96) and nn.CrossEntropyLoss + argmax accuracy counters (train_generator.py:162,
+// 207,231,251,262-267).
+#include "common.hpp"
+
+namespace {
+
+constexpr int kMaxClasses = 16;
+
+struct HeadFwdArgs {
+    const __bf16 *feat;
+    int hw, C, classes;
+    const float *W, *b;
+    const int64_t *targets, *targets2;
+    float loss_weight;
+    int n;
+    float *pooled, *logits, *loss_sum;
+    int *correct, *correct2;
+};
+
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled features [in]
+    __shared__ float red[256];
+    __shared__ float lg[kMaxClasses];
+    const int tid = threadIdx.x, img = blockIdx.x;
+    const int ph = a.hw / 4, in = a.C * ph * ph;
+    // pooled feature index as torch's NCHW flatten: (c*ph + py)*ph + px
+    for (int i = tid; i < in; i += 256) {
+        const int c = i / (ph * ph), r = i - c * ph * ph;
+        const int py = r / ph, px = r - py * ph;
+        float s = 0.f;
+        for (int dy = 0; dy < 4; ++dy)
+            for (int dx = 0; dx < 4; ++dx)
+                s += (float)a.feat[(((long)img * a.hw + py * 4 + dy) * a.hw + px * 4 + dx) * a.C + c];
+        s *= (1.f / 16.f);
+        sm[i] = s;
+        if (a.pooled) a.pooled[(long)img * in + i] = s;
+    }
+    __syncthreads();
+    for (int j = 0; j < a.classes; ++j) {
+        float s = 0.f;
+        for (int i = tid; i < in; i += 256) s = fmaf(sm[i], a.W[(long)j * in + i], s);
+        red[tid] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) red[tid] += red[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            lg[j] = red[0] + a.b[j];
+            a.logits[(long)img * a.classes + j] = lg[j];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float mx = lg[0];
+        int am = 0;
+        for (int j = 1; j < a.classes; ++j)
+            if (lg[j] > mx) {
+                mx = lg[j];
+                am = j;
+            }
+        if (a.targets) {
+            float se = 0.f;
+            for (int j = 0; j < a.classes; ++j) se += expf(lg[j] - mx);
+            const int t = (int)a.targets[img];
+            const float li = logf(se) + mx - lg[t];
+            if (a.loss_sum) atomicAdd(a.loss_sum, a.loss_weight * li / (float)a.n);
+            if (a.correct && am == t) atomicAdd(a.correct, 1);
+        }
+        if (a.targets2 && a.correct2 && am == (int)a.targets2[img]) atomicAdd(a.correct2, 1);
+    }
+}
+
+// dlogits[s][j] = w/n * (softmax - onehot); d_feat = dlogits W / 16 broadcast over each 4x4 window
+__global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float *__restrict__ logits,
+                                                            const int64_t *__restrict__ targets, float loss_weight,
+                                                            int n, int hw, int C, int classes,
+                                                            const float *__restrict__ W, float *__restrict__ dlogits,
+                                                            __bf16 *__restrict__ d_feat) {
+    __shared__ float dl[kMaxClasses];
+    const int tid = threadIdx.x, img = blockIdx.x;
+    if (tid == 0) {
+        const float *lg = logits + (long)img * classes;
+        float mx = lg[0];
+        for (int j = 1; j < classes; ++j) mx = fmaxf(mx, lg[j]);
+        float se = 0.f;
+        for (int j = 0; j < classes; ++j) se += expf(lg[j] - mx);
+        const int t = (int)targets[img];
+        for (int j = 0; j < classes; ++j) {
+            const float v = loss_weight / (float)n * (expf(lg[j] - mx) / se - (j == t ? 1.f : 0.f));
+            dl[j] = v;
+            dlogits[(long)img * classes + j] = v;
+        }
+    }
+    __syncthreads();
+    if (!d_feat) return;
+    const int ph = hw / 4, in = C * ph * ph;
+    // thread per (pixel, 8-channel chunk) of the feature map
+    const int nch = C >> 3;
+    for (int t = tid; t < hw * hw * nch; t += 256) {
+        const int ch = (t % nch) * 8, px = t / nch;
+        const int y = px / hw, x = px - y * hw;
+        const int py = y >> 2, pxx = x >> 2;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int i = ((ch + e) * ph + py) * ph + pxx;
+            float s = 0.f;
+            for (int j = 0; j < classes; ++j) s = fmaf(dl[j], W[(long)j * in + i], s);
+            o[e] = s * (1.f / 16.f);
+        }
+        *reinterpret_cast<uint4 *>(d_feat + (((long)img * hw + y) * hw + x) * C + ch) = pack8(o);
+    }
+}
+
+// dW[j][i] = sum_s dlogits[s][j] * pooled[s][i];  db[j] = sum_s dlogits[s][j]
+__global__ __launch_bounds__(256) void head_bwd_w_kernel(const float *__restrict__ dlogits,
+                                                         const float *__restrict__ pooled, int n, int in, int classes,
+                                                         float *__restrict__ dW, float *__restrict__ db) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i < in) {
+        float s = 0.f;
+        for (int smp = 0; smp < n; ++smp) s = fmaf(dlogits[(long)smp * classes + j], pooled[(long)smp * in + i], s);
+        dW[(long)j * in + i] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int smp = 0; smp < n; ++smp) s += dlogits[(long)smp * classes + j];
+        db[j] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t C, const float *W, const float *b,
+                               int32_t classes, const int64_t *targets, float loss_weight, float *pooled,
+                               float *logits, float *loss_sum, int32_t *correct, const int64_t *targets2,
+                               int32_t *correct2, void *stream) {
+    if (!feat || !W || !b || !logits || n <= 0 || hw < 4 || (hw & 3) || C <= 0 || (C & 7)) return COMBAT_EINVAL;
+    if (classes <= 0 || classes > kMaxClasses) return COMBAT_EINVAL;
+    const int in = C * (hw / 4) * (hw / 4);
+    const int bytes = in * 4;
+    if (bytes > 150 * 1024) return COMBAT_EINVAL;
+    HeadFwdArgs a{reinterpret_cast<const __bf16 *>(feat), hw, C, classes, W, b, targets, targets2, loss_weight, n,
+                  pooled, logits, loss_sum, correct, correct2};
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_fwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr = true;
+    }
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), a);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32_t C, const float *W,
+                               int32_t classes, const float *logits, const int64_t *targets, float loss_weight,
+                               float *dlogits, void *d_feat, float *dW, float *db, void *stream) {
+    if (!W || !logits || !targets || !dlogits || n <= 0 || hw < 4 || (hw & 3) || C <= 0 || (C & 7))
+        return COMBAT_EINVAL;
+    if (classes <= 0 || classes > kMaxClasses) return COMBAT_EINVAL;
+    if (dW && (!db || !pooled)) return COMBAT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(n), dim3(256), 0, st, logits, targets, loss_weight, n, hw, C, classes,
+                       W, dlogits, reinterpret_cast<__bf16 *>(d_feat));
+    CB_LAUNCH_CHECK();
+    if (dW) {
+        const int in = C * (hw / 4) * (hw / 4);
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((in + 255) / 256, classes), dim3(256), 0, st, dlogits, pooled, n, in,
+                           classes, dW, db);
+        CB_LAUNCH_CHECK();
+    }
+    return COMBAT_OK;
+}

@@ -1,0 +1,292 @@
+/*
+ * combat_hip.h -- C ABI of the MI355X (gfx950) kernels behind COMBAT's alternated
+ * generator/surrogate training step.
+ *
+ * The reference (VinAIResearch/COMBAT) has no native code and no FFI: every operator on its
+ * hot path is an ATen call made from Python.  Each entry point below therefore
+ * replaces the ATen operator(s) issued at the cited reference lines; INTEGRATION.md shows the
+ * ctypes stub a maintainer of the reference would add to call them.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless named host_*;
+ *   - the caller owns all memory; kernels allocate nothing and keep no state;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all launches are
+ *     asynchronous and graph-capturable (no sync, no malloc inside);
+ *   - return 0 on success, COMBAT_EINVAL (-1) for an unsupported shape/argument (nothing is
+ *     launched), COMBAT_ELAUNCH (-2) if the HIP launch itself failed;
+ *   - activations: NHWC, bf16, channel count a multiple of 8 ("c8"); images that enter a
+ *     network are NHWC c8 with channels 0..2 = bf16(x) and 3..5 = bf16(x - bf16(x)) (hi/lo
+ *     split, so the first convolution sees ~16 mantissa bits), 6..7 = 0;
+ *   - packed weights: bf16 [rows_pad][kpad], k = tap * C + c, zero padded
+ *     (rows_pad % 128 == 0 or == 16, kpad % 64 == 0);
+ *   - fp32 master weights / gradients: [Cout][R][S][Cin] physical order, i.e. a torch OIHW
+ *     tensor in channels_last memory format (values and state_dict layout unchanged).
+ */
+#ifndef COMBAT_HIP_H
+#define COMBAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COMBAT_OK 0
+#define COMBAT_EINVAL (-1)
+#define COMBAT_ELAUNCH (-2)
+
+/* library identity: "combat_hip gfx950 <abi version>" */
+const char *combat_version(void);
+int combat_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution as gather-GEMM on MFMA (v_mfma_f32_16x16x32_bf16), fused prologue/epilogue.
+ *
+ *   dst[m][n] = epilogue( sum_{tap,c} prologue(src[pix(m,tap)][c]) * wpack[n][tap*C + c] )
+ *
+ * mode 0 (forward)  replaces nn.Conv2d.forward:  preact_resnet.py:21,23,27-29,77;
+ *                   resnet.py:20,22,27-30,72; networks/models.py:275-314; frequency model.py:13-39
+ *         fused prologue replaces the BatchNorm2d/InstanceNorm2d + ReLU/LeakyReLU that feed
+ *         the convolution (preact_resnet.py:33,36; networks/models.py:322-340);
+ *         fused epilogue replaces bias add, `out += shortcut` (preact_resnet.py:39), tanh
+ *         (models.py:340) and the batch statistics of the following norm layer.
+ * mode 1 (dgrad)    replaces the input-gradient half of conv backward (autograd of the same
+ *         lines); fused epilogue replaces the ReLU/LeakyReLU mask, the eval-BatchNorm scale,
+ *         gradient accumulation over branches and the two reductions of norm backward.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct combat_conv_args {
+    /* geometry: src is N x H x W x C, dst is N x P x Q x K (both NHWC bf16, C,K % 8 == 0) */
+    int32_t N, H, W, C;
+    int32_t P, Q, K;
+    int32_t R, S, stride, pad;   /* R==S in {1,3}; stride in {1,2} */
+    int32_t mode;                /* 0 forward, 1 dgrad (src = dY, dst = dX) */
+    const void *src;             /* bf16 */
+    const void *wpack;           /* bf16 [rows_pad][kpad] (rows = K) */
+    int32_t kpad;                /* padded reduction length of wpack, multiple of 64 */
+    int32_t rows_pad;            /* padded row count of wpack */
+    void *dst;                   /* bf16 */
+    /* prologue on src: v = src*scale[g][c] + shift[g][c] (if pro_scale), then
+       v = v > 0 ? v : v*pro_slope (if pro_act); padding stays exactly 0.
+       g = image index * pro_group_stride / C  (stride 0: per-channel, BatchNorm;
+       stride C: per-(image,channel), InstanceNorm) */
+    const float *pro_scale, *pro_shift;
+    int32_t pro_group_stride;
+    int32_t pro_act;
+    float pro_slope;
+    /* epilogue, applied in this order on the fp32 accumulator v of dst[m][n]: */
+    const float *bias;           /* v += bias[n]                                  (may be NULL) */
+    const void *add_pre;         /* v += add_pre[m][n]   bf16, dst-shaped         (may be NULL) */
+    const void *mask_x;          /* bf16 dst-shaped: q = mask_x*mask_scale[g][n] + mask_shift[g][n];
+                                    v *= (q > 0 ? 1 : mask_slope)                 (may be NULL) */
+    const float *mask_scale, *mask_shift;   /* NULL scale => q = mask_x */
+    int32_t mask_group_stride;
+    float mask_slope;
+    int32_t mask_mul_scale;      /* also v *= mask_scale[g][n] (eval-mode BatchNorm backward) */
+    const void *add_post;        /* v += add_post[m][n]  bf16, dst-shaped         (may be NULL) */
+    int32_t tanh_out;            /* v = tanh(v) */
+    /* statistics of the stored (bf16-rounded) values, per granule of `stats_granule` rows:
+       stats_kind 1: (sum v, sum v*v);  2: (sum v, sum v*xh) with xh = mask_x*xh_scale + xh_shift.
+       layout fp32 [ceil(M/granule)][2][K]; granule is fixed by the tile (query below). */
+    int32_t stats_kind;
+    float *stats;
+    const float *xh_scale, *xh_shift;       /* group stride = mask_group_stride */
+    int32_t tile;                /* 0 = auto; else a COMBAT_TILE_* value */
+} combat_conv_args;
+
+#define COMBAT_TILE_128x128 1
+#define COMBAT_TILE_128x64 2
+#define COMBAT_TILE_64x64 3
+#define COMBAT_TILE_128x16 4
+#define COMBAT_TILE_64x128 5
+
+int combat_conv_gemm(const combat_conv_args *a, void *stream);
+/* tile the launcher would pick for these args (a->tile honoured) and its stats granule */
+int combat_conv_pick_tile(const combat_conv_args *a);
+int combat_conv_stats_granule(int tile);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight gradient: dW[n][tap][c] += sum_m dy[m][n] * prologue(src[pix(m,tap)][c])
+ * replaces the weight-gradient half of conv backward for the same reference lines.
+ * dw is fp32 [k_real][R*S][c_real] and must be zeroed by the caller (split-K partial sums are
+ * accumulated with fp32 atomics).  c_real < C folds the hi/lo image channels: channel c of
+ * src contributes to dw channel c % c_real for c < 2*c_real, others are dropped.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct combat_wgrad_args {
+    int32_t N, H, W, C;          /* src (conv input) */
+    int32_t P, Q, K;             /* dy  (conv output gradient) */
+    int32_t R, S, stride, pad;
+    const void *src;             /* bf16 NHWC */
+    const void *dy;              /* bf16 NHWC */
+    float *dw;                   /* fp32 [k_real][R*S][c_real] */
+    int32_t k_real;              /* real output channels (dy channels >= k_real are padding) */
+    int32_t c_real;
+    const float *pro_scale, *pro_shift;
+    int32_t pro_group_stride;
+    int32_t pro_act;
+    float pro_slope;
+    int32_t split;               /* 0 = auto: number of pixel ranges */
+} combat_wgrad_args;
+
+int combat_conv_wgrad(const combat_wgrad_args *a, void *stream);
+
+/* fp32 [K][taps][c_real] master weights -> bf16 packed operands.
+ * wf: forward  [rows_pad(K)][kpad_f], k = tap*C + c   (C = padded channel count, hi/lo dup if dup_hilo)
+ * wd: dgrad    [rows_pad(C)][kpad_d], k = tap*K + n   (may be NULL)
+ * replaces nothing in the reference (layout preparation for the two kernels above). */
+int combat_pack_weights(const float *w, int32_t K, int32_t taps, int32_t c_real, int32_t C, int32_t dup_hilo,
+                        void *wf, int32_t rows_pad_f, int32_t kpad_f,
+                        void *wd, int32_t rows_pad_d, int32_t kpad_d, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation statistics (BatchNorm2d train: preact_resnet.py:20,22; InstanceNorm2d:
+ * networks/models.py:278-313).  `partials` is the [rows][2][C] array written by the conv
+ * epilogue (or by combat_group_stats); group g owns rows [g*rows_per_group, (g+1)*rows_per_group).
+ * Outputs per (g, c): mean, rstd = 1/sqrt(var_biased + eps), and the conv-prologue pair
+ * scale = gamma*rstd, shift = beta - mean*scale (gamma/beta NULL => 1/0).
+ * If running_mean/var are given (groups must be 1) they are updated in place with `momentum`
+ * and the unbiased variance, as nn.BatchNorm2d does; num_batches_tracked (int64) is bumped.
+ * ------------------------------------------------------------------------------------------ */
+int combat_norm_finalize(const float *partials, int32_t groups, int32_t rows_per_group, int32_t C,
+                         float count, float eps, const float *gamma, const float *beta,
+                         float *mean, float *rstd, float *scale, float *shift,
+                         float *running_mean, float *running_var, float momentum,
+                         int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes, void *stream);
+/* rows_per_group > 128 is reduced in two launches through `scratch`
+ * (>= combat_norm_scratch_bytes(groups, C) bytes); smaller problems ignore it (may be NULL). */
+int64_t combat_norm_scratch_bytes(int32_t groups, int32_t C);
+
+/* eval-mode BatchNorm folded to scale/shift from running statistics (preact_resnet.py:33,36 under
+ * netC.eval(), train_generator.py:217) */
+int combat_bn_eval_fold(const float *gamma, const float *beta, const float *running_mean,
+                        const float *running_var, float eps, int32_t C, float *scale, float *shift,
+                        void *stream);
+
+/* column sums of x (and x*x) over runs of rows_per_group rows, for tensors whose normalisation
+ * groups do not align with a conv tile granule (or whose producer is not a conv):
+ * x bf16 [groups*rows_per_group][C] -> partials fp32 [groups][2][C]   (rows_per_group <= 64) */
+int combat_group_stats(const void *x, int32_t groups, int32_t rows_per_group, int32_t C,
+                       float *partials, void *stream);
+
+/* Norm backward, reduction half.  partials: [rows][2][C] = (sum dz, sum dz*xhat) per granule.
+ * Produces the coefficients of  dx = ca*dz + cb*x + cc  per (g, c):
+ *   ca = gamma*rstd, cb = -gamma*rstd^2*m2, cc = gamma*rstd*(mean*rstd*m2 - m1),
+ *   m1 = sum(dz)/count, m2 = sum(dz*xhat)/count;
+ * and (if dgamma/dbeta given, groups == 1)  dgamma = sum dz*xhat, dbeta = sum dz. */
+int combat_norm_bwd_finalize(const float *partials, int32_t groups, int32_t rows_per_group, int32_t C,
+                             float count, const float *gamma, const float *mean, const float *rstd,
+                             float *ca, float *cb, float *cc, float *dgamma, float *dbeta,
+                             float *scratch, int64_t scratch_bytes, void *stream);
+
+/* Norm backward, apply half: dx = ca[g][c]*dz + cb[g][c]*x + cc[g][c] (+ add), bf16 in/out,
+ * rows = groups_rows_total, group of row r = r / rows_per_group (stride 0 => single group). */
+int combat_norm_bwd_apply(const void *dz, const void *x, const void *add, void *dx, int64_t rows,
+                          int32_t C, int32_t rows_per_group, int32_t grouped,
+                          const float *ca, const float *cb, const float *cc, void *stream);
+
+/* per-part (sum dz, sum dz*xhat), same layout as combat_group_stats:
+ * xhat = x*xh_scale[i][c] + xh_shift[i][c], i = part / parts_per_image (0 => i = 0) */
+int combat_group_stats_bwd(const void *dz, const void *x, int32_t groups, int32_t rows_per_group,
+                           int32_t C, int32_t parts_per_image, const float *xh_scale, const float *xh_shift,
+                           float *partials, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * UNet decoder glue (networks/models.py:329-339):
+ *   out = LeakyReLU_0.2( bilinear_up2x( y*sy[g][c] + ty[g][c]  [+ LeakyReLU(s*ss[g][c] + ts[g][c])] ) )
+ * y, s: bf16 [N][H][W][C]; out: bf16 [N][2H][2W][C]; `u` (may be NULL) receives the pre-upsample
+ * sum (bf16, [N][H][W][C]) when the caller needs it.  align_corners=False, as nn.Upsample.
+ * The backward takes d_out and returns du = adjoint_up( d_out * lrelu'(out) ).
+ * ------------------------------------------------------------------------------------------ */
+int combat_unet_up_fwd(const void *y, const float *sy, const float *ty, const void *s, const float *ss,
+                       const float *ts, int32_t N, int32_t H, int32_t W, int32_t C, void *out, void *stream);
+int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N, int32_t H, int32_t W, int32_t C,
+                       void *du, void *stream);
+/* same sum without upsampling (level 0: u1 = IN(upconv1_0) + f0 feeds up() only, but the
+ * encoder skip needs d(skip) = du * lrelu'(skip pre-activation) -- handled by conv epilogues) */
+
+/* ------------------------------------------------------------------------------------------
+ * Trigger: low_freq -> clamp-mix -> Gaussian blur (train_generator.py:47-55, 190-194, 224-226)
+ *   lf  = P * noise * P^T           per image, per channel (P fp32 [hw][hw], see oracle.lowpass_matrix)
+ *   bd  = clamp(x + lf*noise_rate, -1, 1)
+ *   out = blur3x3(bd; k1[3] normalised 1-D kernel, reflect padding)
+ * noise: bf16 NHWC c8 (channels 0..2) -- the generator's tanh output; x, out: fp32 NCHW [n][3][hw][hw].
+ * out_c8 (may be NULL): the same result as the NHWC c8 hi/lo image the classifier stem reads.
+ * mse_partial (may be NULL): fp32 [n] per-image sum (out - x)^2 (MSELoss, train_generator.py:234).
+ * Backward: d_noise (bf16 NHWC c8) from d_out (fp32 NCHW) [+ 2*l2_scale*(out-x) MSE term].
+ * ------------------------------------------------------------------------------------------ */
+int combat_trigger_fwd(const float *x, const void *noise, const float *P, const float *k1, float noise_rate,
+                       int32_t n, int32_t hw, float *out, void *out_c8, float *mse_partial, void *stream);
+int combat_trigger_bwd(const float *x, const void *noise, const float *P, const float *k1, float noise_rate,
+                       int32_t n, int32_t hw, const float *d_out, const float *out, float l2_scale,
+                       void *d_noise, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PostTensorTransform (utils/dataloader.py:45-60): per-sample crop(pad, integer offset) ->
+ * rotation(bilinear, zeros, about the centre) -> horizontal flip, in one gather.
+ * params: fp32 [n][4] = (crop_dx - pad, crop_dy - pad, angle_radians, flip) ; NULL = identity.
+ * src_index (may be NULL): int32 [n] gather of the batch (train_generator.py:195 reorder).
+ * x fp32 NCHW [*][3][hw][hw] -> out_c8 bf16 NHWC c8 hi/lo (and out_f32 NCHW if not NULL).
+ * Backward: d_c8 bf16 NHWC c8 (channels 0..2 = gradient w.r.t. the image) -> d_x fp32 NCHW.
+ * ------------------------------------------------------------------------------------------ */
+int combat_augment_fwd(const float *x, const int32_t *src_index, const float *params, int32_t n, int32_t hw,
+                       void *out_c8, float *out_f32, void *stream);
+int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const float *params, int32_t n, int32_t hw,
+                       float *d_x, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Classifier head: avg_pool(4) -> flatten -> Linear -> CrossEntropyLoss(mean)
+ * (preact_resnet.py:99-101, resnet.py:93-96, train_generator.py:162,207,231,251).
+ * feat bf16 [n][hw][hw][C] (hw = 4*ph), pooled features ordered (c, py, px) as torch's
+ * NCHW flatten, written to `pooled` fp32 [n][in] (may be NULL).  Outputs logits fp32 [n][classes];
+ * loss_sum += weight * sum_i CE_i / n (atomic); correct += #argmax==targets (int32 atomic);
+ * correct2 += #argmax==targets2 (both optional; classes <= 16).
+ * Backward: dlogits fp32 [n][classes] = loss_weight/n * (softmax - onehot);
+ * d_feat bf16 [n][hw][hw][C] = dlogits W / 16 (may be NULL); and (if dW != NULL)
+ * dW fp32 [classes][in] = dlogits^T pooled, db fp32 [classes] (both overwritten).
+ * ------------------------------------------------------------------------------------------ */
+int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t C, const float *W, const float *b,
+                    int32_t classes, const int64_t *targets, float loss_weight, float *pooled, float *logits,
+                    float *loss_sum, int32_t *correct, const int64_t *targets2, int32_t *correct2,
+                    void *stream);
+int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32_t C, const float *W, int32_t classes,
+                    const float *logits, const int64_t *targets, float loss_weight, float *dlogits,
+                    void *d_feat, float *dW, float *db, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SGD(momentum, weight_decay, nesterov) over a list of tensors (train_generator.py:123,125,212,255;
+ * torch.optim.SGD semantics: g += wd*p; buf = first ? g : mu*buf + g; p -= lr*(g + mu*buf)).
+ * ptrs: DEVICE array of 3*count pointers (param, grad, buf triples); sizes: DEVICE int64[count].
+ * grad_scale multiplies the gradient first (1/world_size after an all-reduce sum).
+ * ------------------------------------------------------------------------------------------ */
+int combat_sgd_nesterov(const void *ptrs, const int64_t *sizes, int32_t count, int64_t max_size, float lr,
+                        float momentum, float weight_decay, float grad_scale, int32_t first_step,
+                        void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small data-movement kernels
+ * ------------------------------------------------------------------------------------------ */
+/* fp32 NCHW [n][c][h][w] -> bf16 NHWC c8 hi/lo image (c == 3) */
+int combat_image_to_c8(const float *x, int32_t n, int32_t hw, void *out_c8, void *stream);
+/* bf16 NHWC [rows][C] channels [0, c) -> fp32 NCHW [n][c][h][w] */
+int combat_nhwc_to_nchw_f32(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, int32_t c, float *out,
+                            void *stream);
+/* fp32 NCHW -> bf16 NHWC with C padded to a multiple of 8 */
+int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t C, void *out,
+                             void *stream);
+/* column sums of a bf16 [rows][C] tensor into fp32 out[c_out] (overwritten): conv bias gradient */
+int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream);
+/* 2x2 max pool, bf16 NHWC (frequency model.py:21,32,43) */
+int combat_maxpool2(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, void *out, void *stream);
+/* y = BN_eval(ELU(x)) elementwise per channel, bf16 in/out (frequency model.py:14-16) */
+int combat_elu_affine(const void *x, int64_t rows, int32_t C, const float *scale, const float *shift, void *out,
+                      void *stream);
+/* DCT-II of the truncated 0..255 image (train_generator.py:245): x fp32 NCHW in [-1,1] ->
+ * out bf16 NHWC c8 hi/lo of D*q*D^T, q = trunc((x+1)/2*255); D fp32 [hw][hw] */
+int combat_dct_u8(const float *x, const float *D, int32_t n, int32_t hw, void *out_c8, void *stream);
+/* plain fp32 linear head without pooling/loss: logits = flatten_chw(x) W^T + b  (frequency model.py:46-47) */
+int combat_linear_nhwc(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, const float *W, const float *b,
+                       int32_t classes, float *logits, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMBAT_HIP_H */

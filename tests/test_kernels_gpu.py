@@ -1,0 +1,534 @@
+"""Kernel-level parity on the MI355X: every C-ABI entry point against a plain fp32 PyTorch
+reference of the same operator, computed on the CPU from the same (bf16-rounded) inputs.
+
+Tolerances: bf16 storage has 8 significant bits, so a stored output is compared with
+rel-L2 <= 4e-3 (pure rounding of the result) unless the test says otherwise; fp32 outputs
+(statistics, gradients of weights, logits) with rel-L2 <= 2e-3 or tighter.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+bf16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from combat_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.to("cuda")
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def nhwc(x):  # fp32 NCHW (cpu) -> bf16 NHWC (cuda)
+    return dev(x.permute(0, 2, 3, 1).contiguous().to(bf16))
+
+
+def nchw(x):  # bf16 NHWC (cuda) -> fp32 NCHW (cpu)
+    return x.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rb(x):  # round to bf16 and back (what the kernel reads)
+    return x.to(bf16).float()
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def make_conv(ops, k, c, r, stride, pad, seed, c_pad=None, dup=False):
+    w = torch.randn(k, c, r, r, generator=g(seed)) * (1.0 / math.sqrt(c * r * r))
+    wd = dev(w).contiguous(memory_format=torch.channels_last)
+    pc = ops.PackedConv(wd, stride, pad, c_pad or c, dup_hilo=dup)
+    pc.pack()
+    return w, pc
+
+
+CONV_CASES = [
+    # n, hw, c, k, r, stride, pad, tile
+    (4, 32, 64, 64, 3, 1, 1, 0),
+    (4, 32, 64, 64, 3, 1, 1, 3),      # 64x64 tile
+    (2, 32, 64, 128, 3, 2, 1, 0),
+    (2, 32, 64, 128, 1, 2, 0, 0),     # 1x1 stride-2 shortcut
+    (8, 16, 128, 128, 3, 1, 1, 1),    # 128x128 tile
+    (8, 16, 128, 128, 3, 1, 1, 5),    # 64x128 tile
+    (8, 4, 512, 512, 3, 1, 1, 0),     # layer4 shape: skinny M
+    (3, 5, 64, 64, 3, 1, 1, 0),       # ragged M (75 rows)
+    (6, 2, 512, 512, 3, 1, 1, 0),     # UNet bottleneck 2x2
+]
+
+
+@pytest.mark.parametrize("n,hw,c,k,r,stride,pad,tile", CONV_CASES)
+def test_conv_forward_plain(ops, n, hw, c, k, r, stride, pad, tile):
+    x = torch.randn(n, c, hw, hw, generator=g(1))
+    w, pc = make_conv(ops, k, c, r, stride, pad, 2)
+    p, q = pc.out_hw(hw, hw)
+    y = torch.empty(n, p, q, k, dtype=bf16, device="cuda")
+    ops.conv_launch(ops.conv_args(nhwc(x), y, pc, 0, tile=tile))
+    ref = F.conv2d(rb(x), rb(w), stride=stride, padding=pad)
+    assert rel_l2(nchw(y), ref) < 4e-3
+
+
+def test_conv_forward_bn_relu_prologue_residual_stats(ops):
+    """PreAct conv2: relu(bn(x)) prologue, `out += shortcut` epilogue, next-BN statistics."""
+    n, hw, c = 4, 16, 128
+    x = torch.randn(n, c, hw, hw, generator=g(3)) * 2 + 0.5
+    sc = torch.rand(c, generator=g(4)) + 0.5
+    sh = torch.randn(c, generator=g(5)) * 0.3
+    res = torch.randn(n, c, hw, hw, generator=g(6))
+    w, pc = make_conv(ops, c, c, 3, 1, 1, 7)
+    y = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(x), y, pc, 0, pro=ops.Affine(dev(sc), dev(sh), 0, True, 0.0), add_post=nhwc(res),
+                      stats_kind=1)
+    tile, gran = ops.conv_tile_granule(a)
+    rows = (n * hw * hw + gran - 1) // gran
+    stats = torch.zeros(rows, 2, c, device="cuda")
+    a.stats = stats.data_ptr()
+    ops.conv_launch(a)
+    torch.cuda.synchronize()
+    act = rb(F.relu(rb(x) * sc[None, :, None, None] + sh[None, :, None, None]))
+    ref = F.conv2d(act, rb(w), padding=1) + rb(res)
+    assert rel_l2(nchw(y), ref) < 4e-3
+    yr = nchw(y)
+    s = stats.sum(0).cpu()
+    assert rel_l2(s[0], yr.sum((0, 2, 3))) < 1e-4
+    assert rel_l2(s[1], (yr * yr).sum((0, 2, 3))) < 1e-4
+
+
+def test_conv_forward_instnorm_leaky_bias_tanh(ops):
+    """UNet: per-(image, channel) affine + LeakyReLU(0.2) prologue, bias, tanh, K=3 padded to 8."""
+    n, hw, c = 5, 16, 64
+    x = torch.randn(n, c, hw, hw, generator=g(8))
+    sc = torch.rand(n, c, generator=g(9)) + 0.5
+    sh = torch.randn(n, c, generator=g(10)) * 0.3
+    w = torch.randn(3, c, 3, 3, generator=g(11)) * 0.05
+    b = torch.randn(3, generator=g(12)) * 0.1
+    pc = ops.PackedConv(dev(w).contiguous(memory_format=torch.channels_last), 1, 1, c)
+    pc.pack()
+    b8 = torch.zeros(8)
+    b8[:3] = b
+    y = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+    ops.conv_launch(ops.conv_args(nhwc(x), y, pc, 0, pro=ops.Affine(dev(sc), dev(sh), c, True, 0.2), bias=dev(b8),
+                                  tanh_out=True))
+    act = rb(F.leaky_relu(rb(x) * sc[:, :, None, None] + sh[:, :, None, None], 0.2))
+    ref = torch.tanh(F.conv2d(act, rb(w), b, padding=1))
+    out = nchw(y)
+    assert rel_l2(out[:, :3], ref) < 4e-3
+    assert float(out[:, 3:].abs().max()) == 0.0
+
+
+def test_conv_forward_hilo_stem(ops):
+    """3-channel image as c8 hi/lo split: the stem sees ~16 mantissa bits of the pixels."""
+    n, hw = 4, 32
+    x = torch.rand(n, 3, hw, hw, generator=g(13)) * 2 - 1
+    w, pc = make_conv(ops, 64, 3, 3, 1, 1, 14, c_pad=8, dup=True)
+    xc8 = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+    ops.image_to_c8(dev(x), xc8)
+    y = torch.empty(n, hw, hw, 64, dtype=bf16, device="cuda")
+    ops.conv_launch(ops.conv_args(xc8, y, pc, 0))
+    ref = F.conv2d(x, rb(w), padding=1)  # un-rounded image
+    assert rel_l2(nchw(y), ref) < 3e-3
+    y2 = torch.empty(n, 16, 16, 64, dtype=bf16, device="cuda")  # stride 2 (UNet conv0_0)
+    w2, pc2 = make_conv(ops, 64, 3, 3, 2, 1, 15, c_pad=8, dup=True)
+    ops.conv_launch(ops.conv_args(xc8, y2, pc2, 0))
+    assert rel_l2(nchw(y2), F.conv2d(x, rb(w2), stride=2, padding=1)) < 3e-3
+
+
+@pytest.mark.parametrize("n,hw,c,k,r,stride,pad", [
+    (4, 16, 64, 64, 3, 1, 1), (2, 32, 64, 128, 3, 2, 1), (2, 32, 64, 128, 1, 2, 0), (8, 4, 512, 512, 3, 1, 1),
+    (3, 6, 128, 256, 3, 2, 1), (4, 32, 3, 64, 3, 1, 1), (4, 16, 64, 3, 3, 1, 1)])
+def test_conv_dgrad_and_wgrad(ops, n, hw, c, k, r, stride, pad):
+    c_pad = 8 if c == 3 else c
+    x = torch.randn(n, c, hw, hw, generator=g(20))
+    w, pc = make_conv(ops, k, c, r, stride, pad, 21, c_pad=c_pad, dup=(c == 3))
+    p, q = pc.out_hw(hw, hw)
+    dy = torch.randn(n, k, p, q, generator=g(22))
+    kc = pc.Kc
+    dy_d = torch.zeros(n, p, q, kc, dtype=bf16, device="cuda")
+    dy_d[..., :k] = nhwc(dy)
+    xr = rb(x).requires_grad_(True)
+    wr = rb(w).requires_grad_(True)
+    F.conv2d(xr, wr, stride=stride, padding=pad).backward(rb(dy))
+    dx = torch.empty(n, hw, hw, c_pad, dtype=bf16, device="cuda")
+    ops.conv_launch(ops.conv_args(dy_d, dx, pc, 1))
+    assert rel_l2(nchw(dx)[:, :c], xr.grad) < 4e-3
+    if c == 3:
+        xin = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+        ops.image_to_c8(dev(rb(x)), xin)
+    else:
+        xin = nhwc(x)
+    dw = torch.zeros(k, r * r, c, device="cuda")
+    ops.conv_wgrad(xin, dy_d, pc, dw)
+    ref = wr.grad.permute(0, 2, 3, 1).reshape(k, r * r, c)
+    assert rel_l2(dw, ref) < 2e-3
+
+
+def test_conv_dgrad_epilogue_mask_stats(ops):
+    """Train-mode BN backward, reduction half fused into dgrad: dz = (dgrad + add_pre) * relu'(bn(x)),
+    partial sums of dz and dz*xhat; eval-mode variant multiplies by the BN scale and adds the
+    identity-shortcut gradient."""
+    n, hw, c = 4, 16, 128
+    w, pc = make_conv(ops, c, c, 3, 1, 1, 30)
+    dy = torch.randn(n, c, hw, hw, generator=g(31))
+    xpre = torch.randn(n, c, hw, hw, generator=g(32))
+    extra = torch.randn(n, c, hw, hw, generator=g(33))
+    post = torch.randn(n, c, hw, hw, generator=g(34))
+    sc = torch.rand(c, generator=g(35)) + 0.5
+    sh = torch.randn(c, generator=g(36)) * 0.3
+    mean = torch.randn(c, generator=g(37)) * 0.1
+    rstd = torch.rand(c, generator=g(38)) + 0.5
+    xh_s, xh_b = rstd, -mean * rstd
+    da = torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1) + rb(extra)
+    msk = ((rb(xpre) * sc[None, :, None, None] + sh[None, :, None, None]) > 0).float()
+    dz_ref = da * msk
+    dz = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(dy), dz, pc, 1, add_pre=nhwc(extra), mask_x=nhwc(xpre),
+                      mask=ops.Affine(dev(sc), dev(sh), 0, True, 0.0), stats_kind=2, xh_scale=dev(xh_s),
+                      xh_shift=dev(xh_b))
+    tile, gran = ops.conv_tile_granule(a)
+    stats = torch.zeros((n * hw * hw + gran - 1) // gran, 2, c, device="cuda")
+    a.stats = stats.data_ptr()
+    ops.conv_launch(a)
+    assert rel_l2(nchw(dz), dz_ref) < 4e-3
+    dzr = nchw(dz)
+    xhat = rb(xpre) * xh_s[None, :, None, None] + xh_b[None, :, None, None]
+    s = stats.sum(0).cpu()
+    assert rel_l2(s[0], dzr.sum((0, 2, 3))) < 1e-4
+    assert rel_l2(s[1], (dzr * xhat).sum((0, 2, 3))) < 1e-4
+    # eval-mode: dx = (dgrad) * mask * scale + post
+    dx = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    ops.conv_launch(ops.conv_args(nhwc(dy), dx, pc, 1, mask_x=nhwc(xpre), mask=ops.Affine(dev(sc), dev(sh), 0, True, 0.0),
+                                  mask_mul_scale=True, add_post=nhwc(post)))
+    ref = torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1) * msk * sc[None, :, None, None] + rb(post)
+    assert rel_l2(nchw(dx), ref) < 4e-3
+
+
+def test_wgrad_with_prologue(ops):
+    n, hw, c, k = 4, 16, 64, 128
+    x = torch.randn(n, c, hw, hw, generator=g(40))
+    sc = torch.rand(n, c, generator=g(41)) + 0.5
+    sh = torch.randn(n, c, generator=g(42)) * 0.3
+    w, pc = make_conv(ops, k, c, 3, 2, 1, 43)
+    dy = torch.randn(n, k, 8, 8, generator=g(44))
+    act = rb(F.leaky_relu(rb(x) * sc[:, :, None, None] + sh[:, :, None, None], 0.2))
+    ref = torch.nn.grad.conv2d_weight(act, (k, c, 3, 3), rb(dy), stride=2, padding=1)
+    dw = torch.zeros(k, 9, c, device="cuda")
+    ops.conv_wgrad(nhwc(x), nhwc(dy), pc, dw, pro=ops.Affine(dev(sc), dev(sh), c, True, 0.2))
+    assert rel_l2(dw, ref.permute(0, 2, 3, 1).reshape(k, 9, c)) < 2e-3
+
+
+def test_pack_weights_layouts(ops):
+    k, c = 24, 16
+    w = torch.randn(k, c, 3, 3, generator=g(50))
+    pc = ops.PackedConv(dev(w).contiguous(memory_format=torch.channels_last), 1, 1, c)
+    pc.pack()
+    wf = pc.wf.float().cpu()
+    ref = rb(w).permute(0, 2, 3, 1).reshape(k, 9 * c)
+    assert torch.equal(wf[:k, :9 * c], ref)
+    assert float(wf[k:].abs().max()) == 0 and float(wf[:, 9 * c:].abs().max()) == 0
+    wd = pc.wd.float().cpu()
+    refd = rb(w).permute(1, 2, 3, 0).reshape(c, 9 * k)
+    assert torch.equal(wd[:c, :9 * k], refd)
+
+
+# ---------------------------------------------------------------- normalisation
+
+
+def test_norm_finalize_batchnorm_and_running_stats(ops):
+    rows, c, gran = 4096, 64, 32
+    x = torch.randn(rows * 1, c, generator=g(60)) * 1.7 + 0.8
+    xb = dev(x.to(bf16))
+    parts = rows // gran
+    partials = torch.empty(parts, 2, c, device="cuda")
+    ops.group_stats(xb, parts, gran, partials)
+    gamma, beta = torch.rand(c, generator=g(61)) + 0.5, torch.randn(c, generator=g(62))
+    rm, rv = dev(torch.zeros(c)), dev(torch.ones(c))
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    mean, rstd, scale, shift = (torch.empty(c, device="cuda") for _ in range(4))
+    scratch = torch.empty(ops.norm_scratch_bytes(1, c) // 4, device="cuda")
+    ops.norm_finalize(partials, 1, parts, c, rows, gamma=dev(gamma), beta=dev(beta), mean=mean, rstd=rstd,
+                      scale=scale, shift=shift, running_mean=rm, running_var=rv, nbt=nbt, scratch=scratch)
+    xr = rb(x)
+    bn = torch.nn.BatchNorm1d(c)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    ref = bn(xr)
+    got = xr * scale.cpu() + shift.cpu()
+    assert rel_l2(got, ref) < 1e-5
+    assert rel_l2(rm, bn.running_mean) < 1e-5 and rel_l2(rv, bn.running_var) < 1e-5
+    assert int(nbt) == 1
+    assert rel_l2(mean, xr.mean(0)) < 1e-5
+    assert rel_l2(rstd, 1 / torch.sqrt(xr.var(0, unbiased=False) + 1e-5)) < 1e-5
+
+
+def test_instance_norm_small_groups_and_backward(ops):
+    """InstanceNorm on 2x2 maps (4 rows per group) forward stats + full backward through
+    finalize/apply, against autograd."""
+    n, hw2, c = 6, 4, 64
+    x = torch.randn(n, hw2, c, generator=g(63)) * 1.3 + 0.2
+    dy = torch.randn(n, hw2, c, generator=g(64))
+    xb, dyb = dev(x.to(bf16)), dev(dy.to(bf16))
+    partials = torch.empty(n, 2, c, device="cuda")
+    ops.group_stats(xb, n, hw2, partials)
+    mean, rstd, scale, shift = (torch.empty(n, c, device="cuda") for _ in range(4))
+    ops.norm_finalize(partials, n, 1, c, hw2, mean=mean, rstd=rstd, scale=scale, shift=shift)
+    xr = rb(x).requires_grad_(True)
+    y = F.instance_norm(xr.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
+    assert rel_l2(xr.detach() * scale.cpu()[:, None] + shift.cpu()[:, None], y) < 1e-5
+    y.backward(rb(dy))
+    xh_shift = -mean * rstd
+    ops.group_stats_bwd(dyb, xb, n, hw2, 1, rstd, xh_shift, partials)
+    ca, cb, cc = (torch.empty(n, c, device="cuda") for _ in range(3))
+    ops.norm_bwd_finalize(partials, n, 1, c, hw2, gamma=None, mean=mean, rstd=rstd, ca=ca, cb=cb, cc=cc)
+    dx = torch.empty(n, hw2, c, dtype=bf16, device="cuda")
+    ops.norm_bwd_apply(dyb, xb, dx, ca, cb, cc, rows_per_group=hw2)
+    assert rel_l2(dx.float(), xr.grad) < 6e-3
+
+
+def test_batchnorm_backward_coefficients(ops):
+    rows, c, gran = 2048, 128, 32
+    x = torch.randn(rows, c, generator=g(65)) * 1.5 + 0.3
+    dz = torch.randn(rows, c, generator=g(66))
+    gamma = torch.rand(c, generator=g(67)) + 0.5
+    xb, dzb = dev(x.to(bf16)), dev(dz.to(bf16))
+    parts = rows // gran
+    partials = torch.empty(parts, 2, c, device="cuda")
+    ops.group_stats(xb, parts, gran, partials)
+    mean, rstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    ops.norm_finalize(partials, 1, parts, c, rows, mean=mean, rstd=rstd)
+    ops.group_stats_bwd(dzb, xb, parts, gran, 0, rstd, -mean * rstd, partials)
+    ca, cb, cc, dg, db = (torch.empty(c, device="cuda") for _ in range(5))
+    ops.norm_bwd_finalize(partials, 1, parts, c, rows, gamma=dev(gamma), mean=mean, rstd=rstd, ca=ca, cb=cb, cc=cc,
+                          dgamma=dg, dbeta=db)
+    dx = torch.empty(rows, c, dtype=bf16, device="cuda")
+    ops.norm_bwd_apply(dzb, xb, dx, ca, cb, cc)
+    xr = rb(x).requires_grad_(True)
+    gp = gamma.clone().requires_grad_(True)
+    bp = torch.zeros(c, requires_grad=True)
+    F.batch_norm(xr, None, None, gp, bp, training=True).backward(rb(dz))
+    assert rel_l2(dx.float(), xr.grad) < 6e-3
+    assert rel_l2(dg, gp.grad) < 1e-4 and rel_l2(db, bp.grad) < 1e-4
+
+
+def test_bn_eval_fold(ops):
+    c = 96
+    gm, bt = torch.rand(c, generator=g(68)) + 0.5, torch.randn(c, generator=g(69))
+    rm, rv = torch.randn(c, generator=g(70)), torch.rand(c, generator=g(71)) + 0.2
+    sc, sh = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    ops.bn_eval_fold(dev(gm), dev(bt), dev(rm), dev(rv), sc, sh)
+    x = torch.randn(5, c, generator=g(72))
+    assert rel_l2(x * sc.cpu() + sh.cpu(), F.batch_norm(x, rm, rv, gm, bt, training=False)) < 1e-6
+
+
+# ---------------------------------------------------------------- UNet glue
+
+
+def test_unet_up_forward_backward(ops):
+    n, hw, c = 3, 8, 64
+    y = torch.randn(n, c, hw, hw, generator=g(80))
+    s = torch.randn(n, c, hw, hw, generator=g(81))
+    sy, ty = torch.rand(n, c, generator=g(82)) + 0.5, torch.randn(n, c, generator=g(83)) * 0.2
+    ss, ts = torch.rand(n, c, generator=g(84)) + 0.5, torch.randn(n, c, generator=g(85)) * 0.2
+    out = torch.empty(n, 2 * hw, 2 * hw, c, dtype=bf16, device="cuda")
+    ops.unet_up_fwd(nhwc(y), dev(sy), dev(ty), out, nhwc(s), dev(ss), dev(ts))
+    u = (rb(y) * sy[:, :, None, None] + ty[:, :, None, None]
+         + F.leaky_relu(rb(s) * ss[:, :, None, None] + ts[:, :, None, None], 0.2)).requires_grad_(True)
+    ref = F.leaky_relu(F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False), 0.2)
+    assert rel_l2(nchw(out), ref) < 4e-3
+    out2 = torch.empty_like(out)
+    ops.unet_up_fwd(nhwc(y), dev(sy), dev(ty), out2)  # no skip
+    ref2 = F.leaky_relu(F.interpolate(rb(y) * sy[:, :, None, None] + ty[:, :, None, None], scale_factor=2,
+                                      mode="bilinear", align_corners=False), 0.2)
+    assert rel_l2(nchw(out2), ref2) < 4e-3
+    # backward uses the sign of the *stored* output
+    d_out = torch.randn(n, c, 2 * hw, 2 * hw, generator=g(86))
+    outr = nchw(out)
+    du = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    ops.unet_up_bwd(nhwc(d_out), out, du)
+    gmask = torch.where(outr > 0, torch.ones_like(outr), torch.full_like(outr, 0.2)) * rb(d_out)
+    uu = torch.zeros(n, c, hw, hw, requires_grad=True)
+    F.interpolate(uu, scale_factor=2, mode="bilinear", align_corners=False).backward(gmask)
+    assert rel_l2(nchw(du), uu.grad) < 4e-3
+
+
+# ---------------------------------------------------------------- trigger / augmentation / DCT
+
+
+@pytest.mark.parametrize("hw,sigma", [(32, 0.35), (32, 0.9), (64, 0.6)])
+def test_trigger_forward_backward(ops, hw, sigma):
+    from oracle import combat_oracle as O
+    n = 5
+    x = ((torch.randint(0, 256, (n, 3, hw, hw), generator=g(90)).float() / 255) - 0.5) / 0.5
+    noise = torch.tanh(torch.randn(n, 3, hw, hw, generator=g(91)) * 3)
+    n8 = torch.zeros(n, hw, hw, 8, dtype=bf16, device="cuda")
+    n8[..., :3] = nhwc(noise)
+    pm = dev(O.lowpass_matrix(hw, 0.65))
+    k1 = dev(O.gaussian_kernel1d(sigma))
+    out = torch.empty(n, 3, hw, hw, device="cuda")
+    out8 = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+    mse = torch.empty(n, device="cuda")
+    ops.trigger_fwd(dev(x), n8, pm, k1, 0.08, out, out8, mse)
+    nz = rb(noise).requires_grad_(True)
+    ref = O.trigger_mix(x, nz, 0.08, 0.65, sigma)
+    assert float((out.cpu() - ref).abs().max()) < 2e-5
+    assert rel_l2(mse, ((ref - x) ** 2).sum((1, 2, 3))) < 1e-4
+    hi, lo = out8[..., :3].float().cpu(), out8[..., 3:6].float().cpu()
+    assert float(((hi + lo).permute(0, 3, 1, 2) - ref).abs().max()) < 3e-5
+    d_out = torch.randn(n, 3, hw, hw, generator=g(92))
+    l2s = 0.02 / ref.numel()
+    (ref * d_out).sum().add(l2s * ((ref - x) ** 2).sum()).backward()
+    dn = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+    ops.trigger_bwd(dev(x), n8, pm, k1, 0.08, dev(d_out), out, l2s, dn)
+    assert rel_l2(nchw(dn)[:, :3], nz.grad) < 4e-3
+
+
+def test_augment_forward_backward(ops):
+    from oracle import combat_oracle as O
+    n, hw = 8, 32
+    x = torch.rand(n, 3, hw, hw, generator=g(95)) * 2 - 1
+    p = O.AugParams(np.array([5, 0, 10, 3, 5, 7, 5, 2], np.int32), np.array([5, 10, 0, 8, 5, 5, 1, 9], np.int32),
+                    np.array([0, 0, 7.5, -9.0, 3.0, 0, -4.0, 10.0], np.float32),
+                    np.array([0, 1, 0, 1, 1, 0, 0, 1], np.int32))
+    perm = torch.tensor([3, 1, 0, 2, 7, 6, 5, 4], dtype=torch.int32)
+    par = torch.tensor(np.stack([p.crop_dx - 5, p.crop_dy - 5, np.radians(p.angle_deg), p.flip], 1).astype(np.float32))
+    out8 = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+    outf = torch.empty(n, 3, hw, hw, device="cuda")
+    ops.augment_fwd(dev(x), n, hw, out8, dev(par), dev(perm), outf)
+    xr = x[perm.long()].clone().requires_grad_(True)
+    ref = O.post_tensor_transform(xr, p)
+    assert float((outf.cpu() - ref).abs().max()) < 2e-5
+    d = torch.randn(n, 3, hw, hw, generator=g(96))
+    ref.backward(rb(d))
+    d8 = torch.zeros(n, hw, hw, 8, dtype=bf16, device="cuda")
+    d8[..., :3] = nhwc(d)
+    dx = torch.empty(n, 3, hw, hw, device="cuda")
+    ops.augment_bwd(d8, n, hw, dx, dev(par))
+    assert float((dx.cpu() - xr.grad).abs().max()) < 2e-5
+    # identity (post_transform_option no_use): exact copy, hi + lo == x to ~2^-16
+    ops.augment_fwd(dev(x), n, hw, out8, None, None, outf)
+    assert torch.equal(outf.cpu(), x)
+    assert float(((out8[..., :3].float() + out8[..., 3:6].float()).cpu().permute(0, 3, 1, 2) - x).abs().max()) < 4e-5
+
+
+def test_dct_u8(ops):
+    from oracle import combat_oracle as O
+    n, hw = 4, 32
+    x = ((torch.randint(0, 256, (n, 3, hw, hw), generator=g(97)).float() / 255) - 0.5) / 0.5 * 0.999
+    out8 = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+    ops.dct_u8(dev(x), dev(O.dct_matrix(hw)), out8)
+    ref = O.frequency_input(x)
+    got = (out8[..., :3].float() + out8[..., 3:6].float()).cpu().permute(0, 3, 1, 2)
+    assert rel_l2(got, ref) < 1e-4
+
+
+# ---------------------------------------------------------------- head / SGD / misc
+
+
+@pytest.mark.parametrize("hw,classes", [(4, 10), (8, 8)])
+def test_head_forward_backward(ops, hw, classes):
+    n, c = 6, 512
+    feat = torch.randn(n, c, hw, hw, generator=g(100))
+    ph = hw // 4
+    w = torch.randn(classes, c * ph * ph, generator=g(101)) * 0.05
+    b = torch.randn(classes, generator=g(102)) * 0.1
+    t = torch.randint(0, classes, (n,), generator=g(103))
+    fb = nhwc(feat)
+    logits = torch.empty(n, classes, device="cuda")
+    pooled = torch.empty(n, c * ph * ph, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    correct = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.head_fwd(fb, dev(w), dev(b), logits, targets=dev(t), loss_weight=0.8, pooled=pooled, loss_sum=loss,
+                 correct=correct)
+    fr = rb(feat).requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    lg = F.linear(F.avg_pool2d(fr, 4).flatten(1), wr, br)
+    ls = 0.8 * F.cross_entropy(lg, t)
+    ls.backward()
+    assert rel_l2(logits, lg) < 1e-5
+    assert abs(float(loss) - float(ls)) < 1e-5
+    assert int(correct) == int((lg.argmax(1) == t).sum())
+    dl = torch.empty(n, classes, device="cuda")
+    dfeat = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    dw, db = torch.empty_like(dev(w)), torch.empty(classes, device="cuda")
+    ops.head_bwd(pooled, n, hw, c, dev(w), logits, dev(t), 0.8, dl, dfeat, dw, db)
+    assert rel_l2(nchw(dfeat), fr.grad) < 4e-3
+    assert rel_l2(dw, wr.grad) < 1e-5 and rel_l2(db, br.grad) < 1e-5
+
+
+def test_sgd_nesterov_multi_tensor(ops):
+    from oracle import combat_oracle as O
+    shapes = [(64, 3, 3, 3), (64,), (128, 64, 3, 3), (10, 512)]
+    ps = [torch.randn(s, generator=g(110 + i)) for i, s in enumerate(shapes)]
+    dps = [dev(p.clone()) for p in ps]
+    dbufs = [torch.zeros_like(p) for p in dps]
+    dgr = [torch.empty_like(p) for p in dps]
+    table = torch.tensor([[p.data_ptr(), gr.data_ptr(), bf.data_ptr()] for p, gr, bf in zip(dps, dgr, dbufs)],
+                         dtype=torch.int64, device="cuda")
+    sizes = torch.tensor([p.numel() for p in dps], dtype=torch.int64, device="cuda")
+    bufs = [None] * len(ps)
+    for step in range(3):
+        gs = [torch.randn(s, generator=g(120 + 10 * step + i)) for i, s in enumerate(shapes)]
+        for d, s in zip(dgr, gs):
+            d.copy_(s * 4)
+        ops.sgd_nesterov(table, sizes, len(ps), max(p.numel() for p in ps), 1e-2, 0.9, 5e-4, 0.25, step == 0)
+        O.sgd_nesterov_step(ps, gs, bufs, 1e-2)
+    for a, b in zip(dps, ps):
+        assert rel_l2(a, b) < 1e-6
+
+
+def test_small_kernels(ops):
+    n, c, hw = 3, 32, 8
+    x = torch.randn(n, c, hw, hw, generator=g(130))
+    xb = nhwc(x)
+    mp = torch.empty(n, hw // 2, hw // 2, c, dtype=bf16, device="cuda")
+    ops.maxpool2(xb, mp)
+    assert torch.equal(nchw(mp), F.max_pool2d(rb(x), 2))
+    sc, sh = torch.rand(c, generator=g(131)) + 0.5, torch.randn(c, generator=g(132))
+    ea = torch.empty_like(xb)
+    ops.elu_affine(xb, dev(sc), dev(sh), ea)
+    assert rel_l2(nchw(ea), F.elu(rb(x)) * sc[None, :, None, None] + sh[None, :, None, None]) < 4e-3
+    cs = torch.empty(c, device="cuda")
+    ops.colsum(xb, c, cs)
+    assert rel_l2(cs, rb(x).sum((0, 2, 3))) < 1e-5
+    w, b = torch.randn(2, c * hw * hw, generator=g(133)) * 0.02, torch.randn(2, generator=g(134))
+    lg = torch.empty(n, 2, device="cuda")
+    ops.linear_nhwc(xb, dev(w), dev(b), lg)
+    assert rel_l2(lg, F.linear(rb(x).flatten(1), w, b)) < 1e-5
+    back = torch.empty(n, 5, hw, hw, device="cuda")
+    ops.nhwc_to_nchw_f32(xb, 5, back)
+    assert torch.equal(back.cpu(), rb(x)[:, :5])
+    img = torch.rand(n, 3, hw, hw, generator=g(135))
+    o16 = torch.empty(n, hw, hw, 16, dtype=bf16, device="cuda")
+    ops.nchw_to_nhwc_bf16(dev(img), o16)
+    assert torch.equal(nchw(o16)[:, :3], rb(img)) and float(o16[..., 3:].float().abs().max()) == 0
+
+
+def test_invalid_arguments_are_rejected(ops):
+    """Error behaviour of the boundary: bad shapes raise, nothing is launched."""
+    from combat_amd._lib import CombatHipError
+    w, pc = make_conv(ops, 64, 64, 3, 1, 1, 140)
+    x = torch.zeros(1, 4, 4, 64, dtype=bf16, device="cuda")
+    y = torch.zeros(1, 4, 4, 64, dtype=bf16, device="cuda")
+    a = ops.conv_args(x, y, pc, 0)
+    a.stride = 3
+    with pytest.raises(CombatHipError):
+        ops.conv_launch(a)
+    a = ops.conv_args(x, y, pc, 0)
+    a.stats_kind = 1  # no stats buffer
+    with pytest.raises(CombatHipError):
+        ops.conv_launch(a)
+    with pytest.raises(CombatHipError):
+        ops.maxpool2(torch.zeros(1, 3, 3, 8, dtype=bf16, device="cuda"), y)
