@@ -29,7 +29,7 @@ class ConvArgs(C.Structure):
         ("bias", c_vp), ("add_pre", c_vp), ("mask_x", c_vp), ("mask_scale", c_vp), ("mask_shift", c_vp),
         ("mask_group_stride", c_i32), ("mask_slope", c_f32), ("mask_mul_scale", c_i32),
         ("add_post", c_vp), ("tanh_out", c_i32),
-        ("stats_kind", c_i32), ("stats", c_vp), ("xh_scale", c_vp), ("xh_shift", c_vp),
+        ("stats_kind", c_i32), ("stats", c_vp), ("xh_mean", c_vp), ("xh_rstd", c_vp),
         ("tile", c_i32),
     ]
 
@@ -69,9 +69,9 @@ SIGNATURES = {
     "combat_unet_up_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_unet_up_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_trigger_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    "combat_trigger_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
+    "combat_trigger_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp]),
     "combat_augment_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
-    "combat_augment_bwd": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "combat_augment_bwd": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "combat_head_fwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
                                   c_vp, c_vp, c_vp]),
     "combat_head_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
@@ -80,6 +80,7 @@ SIGNATURES = {
     "combat_image_to_c8": (C.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "combat_nhwc_to_nchw_f32": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_nchw_to_nhwc_bf16": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_memset_zero": (C.c_int, [c_vp, c_i64, c_vp]),
     "combat_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "combat_maxpool2": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_elu_affine": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),

@@ -313,13 +313,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                     s2[e] = fmaf(vr[e], vr[e], s2[e]);
                 }
             } else {
-                float hs[8], hh[8];
-                load8f(a.xh_scale + g + n, hs);
-                load8f(a.xh_shift + g + n, hh);
+                float hr[8], hm[8];
+                load8f(a.xh_rstd + g + n, hr);
+                load8f(a.xh_mean + g + n, hm);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     s1[e] += vr[e];
-                    s2[e] = fmaf(vr[e], fmaf(xm[e], hs[e], hh[e]), s2[e]);
+                    s2[e] = fmaf(vr[e], (xm[e] - hm[e]) * hr[e], s2[e]);
                 }
             }
         }
@@ -403,7 +403,7 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     if (a->mask_scale && !a->mask_shift) return COMBAT_EINVAL;
     if (a->mask_mul_scale && !a->mask_scale) return COMBAT_EINVAL;
     if (a->stats_kind < 0 || a->stats_kind > 2 || (a->stats_kind && !a->stats)) return COMBAT_EINVAL;
-    if (a->stats_kind == 2 && (!a->mask_x || !a->xh_scale || !a->xh_shift)) return COMBAT_EINVAL;
+    if (a->stats_kind == 2 && (!a->mask_x || !a->xh_mean || !a->xh_rstd)) return COMBAT_EINVAL;
     ConvParams p;
     p.a = *a;
     p.c_shift = ilog2_exact(a->C);

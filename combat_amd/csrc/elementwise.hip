@@ -367,6 +367,12 @@ extern "C" int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, in
     return COMBAT_OK;
 }
 
+extern "C" int combat_memset_zero(void *ptr, int64_t bytes, void *stream) {
+    if (!ptr || bytes < 0) return COMBAT_EINVAL;
+    if (bytes == 0) return COMBAT_OK;
+    return hipMemsetAsync(ptr, 0, (size_t)bytes, as_stream(stream)) == hipSuccess ? COMBAT_OK : COMBAT_ELAUNCH;
+}
+
 extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream) {
     if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || c_out <= 0 || c_out > C) return COMBAT_EINVAL;
     hipLaunchKernelGGL(colsum_kernel, dim3((c_out + 7) / 8), dim3(256), 0, as_stream(stream),

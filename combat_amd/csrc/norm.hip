@@ -131,8 +131,8 @@ __global__ void bn_eval_fold_kernel(const float *gamma, const float *beta, const
 // InstanceNorm group, or a 32-row slab of a larger one -- same layout as the conv epilogue's)
 __global__ __launch_bounds__(256) void group_stats_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dz,
                                                           int groups, int rows_per_group, int C, int parts_per_image,
-                                                          const float *__restrict__ xh_scale,
-                                                          const float *__restrict__ xh_shift,
+                                                          const float *__restrict__ xh_mean,
+                                                          const float *__restrict__ xh_rstd,
                                                           float *__restrict__ part) {
     const int nch = C >> 3;
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const __bf16 *__restri
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     if (dz) {
         const long img = parts_per_image > 0 ? g / parts_per_image : 0;
-        load8f(xh_scale + img * C + c, hs);
-        load8f(xh_shift + img * C + c, hh);
+        load8f(xh_rstd + img * C + c, hs);
+        load8f(xh_mean + img * C + c, hh);
     }
     for (int r = 0; r < rows_per_group; ++r) {
         const long off = ((long)g * rows_per_group + r) * C + c;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void group_stats_kernel(const __bf16 *__restri
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 s1[e] += dv[e];
-                s2[e] = fmaf(dv[e], fmaf(xv[e], hs[e], hh[e]), s2[e]);
+                s2[e] = fmaf(dv[e], (xv[e] - hh[e]) * hs[e], s2[e]);
             }
         } else {
 #pragma unroll
@@ -291,14 +291,14 @@ extern "C" int combat_group_stats(const void *x, int32_t groups, int32_t rows_pe
 }
 
 extern "C" int combat_group_stats_bwd(const void *dz, const void *x, int32_t groups, int32_t rows_per_group,
-                                      int32_t C, int32_t parts_per_image, const float *xh_scale,
-                                      const float *xh_shift, float *partials, void *stream) {
-    if (!dz || !x || !partials || !xh_scale || !xh_shift || parts_per_image < 0) return COMBAT_EINVAL;
+                                      int32_t C, int32_t parts_per_image, const float *xh_mean,
+                                      const float *xh_rstd, float *partials, void *stream) {
+    if (!dz || !x || !partials || !xh_mean || !xh_rstd || parts_per_image < 0) return COMBAT_EINVAL;
     if (groups <= 0 || rows_per_group <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     const long t = (long)groups * (C >> 3);
     hipLaunchKernelGGL(group_stats_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(dz), groups,
-                       rows_per_group, C, parts_per_image, xh_scale, xh_shift, partials);
+                       rows_per_group, C, parts_per_image, xh_mean, xh_rstd, partials);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void trigger_bwd_kernel(const float *__restric
                                                           const float *__restrict__ P, const float *__restrict__ k1,
                                                           float rate, int hw, const float *__restrict__ d_out,
                                                           const float *__restrict__ outp, float l2_scale,
-                                                          uint4 *__restrict__ d_noise) {
+                                                          int pre_tanh, uint4 *__restrict__ d_noise) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hw2 = hw * hw, tid = threadIdx.x, img = blockIdx.x;
     float *Pm = sm, *Kb = sm + hw2, *A = sm + 2 * hw2, *B = sm + 3 * hw2, *G = sm + 4 * hw2, *R = sm + 5 * hw2;
@@ -138,6 +138,13 @@ __global__ __launch_bounds__(256) void trigger_bwd_kernel(const float *__restric
     }
     for (int o = tid; o < hw2; o += 256) {
         uint4 u;
+        if (pre_tanh) {  // noise = tanh(z): hand back the gradient w.r.t. z
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t = (float)noise[((long)img * hw2 + o) * 8 + c];
+                R[c * hw2 + o] *= 1.f - t * t;
+            }
+        }
         u.x = pack_bf16x2(R[o], R[hw2 + o]);
         u.y = pack_bf16x2(R[2 * hw2 + o], 0.f);
         u.z = 0;
@@ -220,10 +227,10 @@ __device__ __forceinline__ void crop_scatter(float *plane, int hw, const AugGeom
 
 __global__ __launch_bounds__(256) void augment_bwd_kernel(const __bf16 *__restrict__ d_c8, int cch,
                                                           const float *__restrict__ params, int hw,
-                                                          float *__restrict__ d_x) {
+                                                          float *__restrict__ d_x, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hw2 = hw * hw, tid = threadIdx.x, img = blockIdx.x;
-    for (int o = tid; o < 3 * hw2; o += 256) sm[o] = 0.f;
+    for (int o = tid; o < 3 * hw2; o += 256) sm[o] = accumulate ? d_x[(long)img * 3 * hw2 + o] : 0.f;
     __syncthreads();
     const AugGeom g = aug_geom(params, img, hw);
     for (int o = tid; o < hw2; o += 256) {
@@ -297,7 +304,7 @@ extern "C" int combat_trigger_fwd(const float *x, const void *noise, const float
 
 extern "C" int combat_trigger_bwd(const float *x, const void *noise, const float *P, const float *k1,
                                   float noise_rate, int32_t n, int32_t hw, const float *d_out, const float *out,
-                                  float l2_scale, void *d_noise, void *stream) {
+                                  float l2_scale, int32_t pre_tanh, void *d_noise, void *stream) {
     if (!x || !noise || !P || !k1 || !d_noise || n < 0 || hw < 16 || hw > 64) return COMBAT_EINVAL;
     if (l2_scale != 0.f && !out) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
@@ -305,7 +312,7 @@ extern "C" int combat_trigger_bwd(const float *x, const void *noise, const float
     if (set_smem(trigger_bwd_kernel, bytes)) return COMBAT_ELAUNCH;
     hipLaunchKernelGGL(trigger_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), x,
                        reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, d_out, out, l2_scale,
-                       reinterpret_cast<uint4 *>(d_noise));
+                       pre_tanh, reinterpret_cast<uint4 *>(d_noise));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -323,13 +330,13 @@ extern "C" int combat_augment_fwd(const float *x, const int32_t *src_index, cons
 }
 
 extern "C" int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const float *params, int32_t n, int32_t hw,
-                                  float *d_x, void *stream) {
+                                  float *d_x, int32_t accumulate, void *stream) {
     if (!d_c8 || !d_x || c8_channels < 3 || n < 0 || hw < 2 || hw > 96) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     const int bytes = 3 * hw * hw * 4;
     if (set_smem(augment_bwd_kernel, bytes)) return COMBAT_ELAUNCH;
     hipLaunchKernelGGL(augment_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream),
-                       reinterpret_cast<const __bf16 *>(d_c8), c8_channels, params, hw, d_x);
+                       reinterpret_cast<const __bf16 *>(d_c8), c8_channels, params, hw, d_x, accumulate);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

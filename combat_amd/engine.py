@@ -1,0 +1,829 @@
+"""Per-network forward/backward schedules over the combat_hip C ABI.
+
+A network is executed as a *plan*: the ordered list of C-ABI calls (arguments marshalled once,
+buffers pre-allocated in a ``Slot``) that the reference's ``module(x)`` / ``loss.backward()``
+expand to, with the normalisation / activation / residual element-wise work folded into the
+convolution prologues and epilogues.  Plans are replayed with no Python work per kernel beyond
+one ctypes call, and are what gets captured into a HIP graph.
+
+Reference call sites: PreActResNet forward classifier_models/preact_resnet.py:32-40, 93-102;
+UnetGenerator forward networks/models.py:321-341; FrequencyModel forward
+defenses/frequency_based/model.py:49-52; their backward passes are what autograd derives.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import CombatHipError, lib
+from .nets import UNET_LAYERS
+from .ops import Affine, PackedConv, bf16
+
+f32 = torch.float32
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Plan:
+    """An ordered list of C-ABI calls with pre-marshalled arguments (stream appended at run)."""
+
+    def __init__(self, name: str):
+        self.name = name
+        self.calls: List[Tuple] = []
+        self._keep: List = []
+
+    def add(self, what: str, cfunc, *args) -> None:
+        self.calls.append((cfunc, args, what))
+
+    def hold(self, *objs) -> None:
+        self._keep.extend(objs)
+
+    def run(self) -> None:
+        st = torch.cuda.current_stream().cuda_stream
+        for cfunc, args, what in self.calls:
+            rc = cfunc(*args, st)
+            if rc:
+                kind = {-1: "invalid shape/argument", -2: "HIP launch failed"}.get(rc, "status %d" % rc)
+                raise CombatHipError("%s/%s: %s" % (self.name, what, kind))
+
+    def __len__(self):
+        return len(self.calls)
+
+
+class Slot:
+    """Named device buffers of one forward(+backward) instance at a fixed batch size."""
+
+    def __init__(self, device, n: int, hw: int):
+        self.device, self.N, self.hw = device, n, hw
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.norm: Dict[str, "NormState"] = {}
+        self.plans: Dict[str, Plan] = {}
+
+    def buf(self, name: str, shape, dtype=bf16, zero: bool = False) -> torch.Tensor:
+        t = self.bufs.get(name)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+            self.bufs[name] = t
+        assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (name, t.shape, shape)
+        return t
+
+
+class NormState:
+    """Statistics of one normalised tensor: per-channel (groups=1) or per-(image, channel)."""
+
+    def __init__(self, slot: Slot, key: str, groups: int, c: int):
+        mk = lambda s: slot.buf("%s.%s" % (key, s), (groups, c), f32)
+        self.groups, self.C = groups, c
+        self.mean, self.rstd, self.scale, self.shift = mk("mean"), mk("rstd"), mk("scale"), mk("shift")
+        self.ca = self.cb = self.cc = None
+        self._slot, self._key = slot, key
+
+    def bwd_coeffs(self):
+        if self.ca is None:
+            mk = lambda s: self._slot.buf("%s.%s" % (self._key, s), (self.groups, self.C), f32)
+            self.ca, self.cb, self.cc = mk("ca"), mk("cb"), mk("cc")
+        return self.ca, self.cb, self.cc
+
+
+class FlatParams:
+    """All parameters of a module re-homed into one fp32 buffer, with same-layout gradient and
+    momentum buffers.  Conv weights are stored [K][R][S][C] (the module keeps seeing them as OIHW
+    tensors with channels_last strides), so the wgrad kernel writes gradients in place, SGD is one
+    launch and the data-parallel all-reduce is one flat tensor (bucketed by offset ranges)."""
+
+    ALIGN = 64  # floats
+
+    def __init__(self, module: torch.nn.Module):
+        params = list(module.named_parameters())
+        dev = params[0][1].device
+        self.offsets: Dict[str, Tuple[int, int, tuple]] = {}
+        off = 0
+        for name, p in params:
+            self.offsets[name] = (off, p.numel(), tuple(p.shape))
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        self.flat = torch.zeros(off, dtype=f32, device=dev)
+        self.grad = torch.zeros(off, dtype=f32, device=dev)
+        self.mom = torch.zeros(off, dtype=f32, device=dev)
+        with torch.no_grad():
+            for name, p in params:
+                o, n, shape = self.offsets[name]
+                dst = self.flat[o:o + n]
+                if p.dim() == 4:
+                    k, c, r, s = shape
+                    dst.copy_(p.detach().permute(0, 2, 3, 1).reshape(-1))
+                    p.data = dst.view(k, r, s, c).permute(0, 3, 1, 2)
+                else:
+                    dst.copy_(p.detach().reshape(-1))
+                    p.data = dst.view(shape)
+        self.sgd_ptrs = torch.tensor([[self.flat.data_ptr(), self.grad.data_ptr(), self.mom.data_ptr()]],
+                                     dtype=torch.int64, device=dev)
+        self.sgd_sizes = torch.tensor([self.total], dtype=torch.int64, device=dev)
+
+    def _slice(self, base: torch.Tensor, name: str) -> torch.Tensor:
+        o, n, _ = self.offsets[name]
+        return base[o:o + n]
+
+    def grad_phys(self, name: str) -> torch.Tensor:
+        """Gradient in the kernel's physical layout ([K][taps][C] for conv weights)."""
+        o, n, shape = self.offsets[name]
+        g = self.grad[o:o + n]
+        if len(shape) == 4:
+            k, c, r, s = shape
+            return g.view(k, r * s, c)
+        return g.view(shape)
+
+    def logical(self, base: torch.Tensor, name: str) -> torch.Tensor:
+        """`base` (grad / momentum) slice viewed with the parameter's logical shape."""
+        o, n, shape = self.offsets[name]
+        g = base[o:o + n]
+        if len(shape) == 4:
+            k, c, r, s = shape
+            return g.view(k, r, s, c).permute(0, 3, 1, 2)
+        return g.view(shape)
+
+    def sgd_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, grad_scale: float = 1.0):
+        """torch.optim.SGD(nesterov=True) on the whole buffer: the momentum buffer starts at zero,
+        so `buf = mu*buf + g` equals torch's first-step `buf = g`."""
+        ops.sgd_nesterov(self.sgd_ptrs, self.sgd_sizes, 1, self.total, lr, momentum, weight_decay, grad_scale, False)
+
+
+# --------------------------------------------------------------------------------------------
+# recording helpers
+# --------------------------------------------------------------------------------------------
+
+
+def rec_conv(plan: Plan, what: str, src, dst, pc: PackedConv, mode: int, **kw):
+    a = ops.conv_args(src, dst, pc, mode, **kw)
+    plan.hold(a)
+    plan.add(what, lib.combat_conv_gemm, ctypes.byref(a))
+    return a
+
+
+def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[Affine] = None):
+    a = ops.WgradArgs()
+    a.N, a.H, a.W, a.C = src.shape
+    _, a.P, a.Q, a.K = dy.shape
+    a.R = a.S = pc.R
+    a.stride, a.pad = pc.stride, pc.pad
+    a.src, a.dy, a.dw, a.k_real, a.c_real = src.data_ptr(), dy.data_ptr(), dw.data_ptr(), pc.K, pc.c_real
+    if pro is not None:
+        a.pro_scale, a.pro_shift = _p(pro.scale), _p(pro.shift)
+        a.pro_group_stride, a.pro_act, a.pro_slope = pro.group_stride, int(pro.act), pro.slope
+    a.split = 0
+    plan.hold(a, src, dy, dw, pro)
+    plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a))
+
+
+def _pow2_part(pq: int, cap: int = 32) -> int:
+    g = 1
+    while g * 2 <= cap and pq % (g * 2) == 0:
+        g *= 2
+    return g
+
+
+class NetEngine:
+    """Shared machinery: parameters, packed operands, scratch, slots."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.module = module
+        self.device = next(module.parameters()).device
+        if self.device.type != "cuda":
+            raise CombatHipError("combat_amd engines run on the GPU only (module is on %s); there is no CPU path"
+                                 % self.device)
+        self.fp = FlatParams(module)
+        self.convs: List[PackedConv] = []
+        self.slots: Dict[Tuple, Slot] = {}
+        self._scratch = torch.empty(ops.norm_scratch_bytes(1, 512) // 4, dtype=f32, device=self.device)
+        self.weights_dirty = True
+
+    def mark_weights_dirty(self) -> None:
+        self.weights_dirty = True
+
+    def slot(self, name: str, n: int, hw: int) -> Slot:
+        key = (name, n, hw)
+        s = self.slots.get(key)
+        if s is None:
+            s = Slot(self.device, n, hw)
+            self.slots[key] = s
+        return s
+
+    def _pc(self, weight, stride, pad, cin_pad, dup=False, need_dgrad=True) -> PackedConv:
+        pc = PackedConv(weight, stride, pad, cin_pad, dup_hilo=dup, need_dgrad=need_dgrad)
+        self.convs.append(pc)
+        return pc
+
+    def refresh(self) -> None:
+        """Re-derive bf16 operands (and folded eval-BN) after a parameter update."""
+        if not self.weights_dirty:
+            return
+        for pc in self.convs:
+            pc.pack()
+        self._refresh_extra()
+        self.weights_dirty = False
+
+    def _refresh_extra(self) -> None:
+        pass
+
+    # ---- normalisation plumbing -----------------------------------------------------------
+    def _conv_norm(self, plan: Plan, slot: Slot, key: str, src, dst, pc: PackedConv, *, groups: int,
+                   gamma=None, beta=None, running=None, **conv_kw) -> NormState:
+        """conv + statistics of its raw output + finalize.  groups == 1: batch statistics
+        (optionally updating running stats); groups == N: instance statistics."""
+        n, p, q, c = dst.shape
+        pq, m = p * q, n * p * q
+        a = ops.conv_args(src, dst, pc, 0, **conv_kw)
+        tile, gran = ops.conv_tile_granule(a)
+        fused = (groups == 1) or (pq % gran == 0)
+        st = slot.norm.get(key)
+        if st is None:
+            st = NormState(slot, key, groups, c)
+            slot.norm[key] = st
+        if fused:
+            rows = (m + gran - 1) // gran
+            part = slot.buf(key + ".part", (rows, 2, c), f32)
+            a.stats_kind, a.stats = 1, part.data_ptr()
+            rpg = rows if groups == 1 else pq // gran
+        plan.hold(a, part if fused else None)
+        plan.add(key + ".conv", lib.combat_conv_gemm, ctypes.byref(a))
+        if not fused:
+            g = _pow2_part(pq)
+            parts = m // g
+            part = slot.buf(key + ".part", (parts, 2, c), f32)
+            plan.add(key + ".stats", lib.combat_group_stats, dst.data_ptr(), parts, g, c, part.data_ptr())
+            rpg = pq // g
+        rm = rv = nbt = None
+        if running is not None:
+            rm, rv, nbt = running
+        plan.hold(gamma, beta, rm, rv, nbt)
+        plan.add(key + ".finalize", lib.combat_norm_finalize, part.data_ptr(), groups, rpg, c, float(m // groups),
+                 1e-5, _p(gamma), _p(beta), st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
+                 st.shift.data_ptr(), _p(rm), _p(rv), 0.1, _p(nbt), self._scratch.data_ptr(),
+                 self._scratch.numel() * 4)
+        return st
+
+    def _dgrad_norm(self, plan: Plan, slot: Slot, key: str, dy, dz, pc: PackedConv, x_pre, st: NormState, *,
+                    group_stride: int, slope: float, gamma=None, dgamma=None, dbeta=None, add_pre=None):
+        """dgrad whose epilogue applies the activation mask of the conv input (recomputed from the
+        saved pre-norm tensor x_pre) and emits the two norm-backward reductions; then finalize to
+        (ca, cb, cc).  Returns nothing: the caller applies the coefficients."""
+        n, p, q, c = dz.shape
+        pq, m = p * q, n * p * q
+        groups = st.groups
+        mask = Affine(st.scale, st.shift, group_stride, True, slope)
+        a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask)
+        tile, gran = ops.conv_tile_granule(a)
+        fused = (groups == 1) or (pq % gran == 0)
+        if fused:
+            rows = (m + gran - 1) // gran
+            part = slot.buf(key + ".bpart", (rows, 2, c), f32)
+            a.stats_kind, a.stats = 2, part.data_ptr()
+            a.xh_mean, a.xh_rstd = st.mean.data_ptr(), st.rstd.data_ptr()
+            rpg = rows if groups == 1 else pq // gran
+        plan.hold(a)
+        plan.add(key + ".dgrad", lib.combat_conv_gemm, ctypes.byref(a))
+        if not fused:
+            part, rpg = self._stats_bwd(plan, slot, key, dz, x_pre, st)
+        self._bwd_finalize(plan, key, part, rpg, m // groups, st, gamma, dgamma, dbeta)
+
+    def _stats_bwd(self, plan: Plan, slot: Slot, key: str, dz, x_pre, st: NormState):
+        n, p, q, c = dz.shape
+        pq, m = p * q, n * p * q
+        g = _pow2_part(pq if st.groups > 1 else m)
+        parts = m // g
+        part = slot.buf(key + ".bpart", (parts, 2, c), f32)
+        ppi = (pq // g) if st.groups > 1 else 0
+        plan.add(key + ".bstats", lib.combat_group_stats_bwd, dz.data_ptr(), x_pre.data_ptr(), parts, g, c, ppi,
+                 st.mean.data_ptr(), st.rstd.data_ptr(), part.data_ptr())
+        return part, (pq // g if st.groups > 1 else parts)
+
+    def _bwd_finalize(self, plan: Plan, key: str, part, rpg: int, count: int, st: NormState, gamma, dgamma, dbeta):
+        ca, cb, cc = st.bwd_coeffs()
+        plan.hold(part, gamma, dgamma, dbeta)
+        plan.add(key + ".bfinalize", lib.combat_norm_bwd_finalize, part.data_ptr(), st.groups, rpg, st.C,
+                 float(count), _p(gamma), st.mean.data_ptr(), st.rstd.data_ptr(), ca.data_ptr(), cb.data_ptr(),
+                 cc.data_ptr(), _p(dgamma), _p(dbeta), self._scratch.data_ptr(), self._scratch.numel() * 4)
+
+    @staticmethod
+    def _bwd_apply(plan: Plan, key: str, dz, x_pre, dx, st: NormState, add=None):
+        n, p, q, c = dz.shape
+        grouped = int(st.groups > 1)
+        ca, cb, cc = st.bwd_coeffs()
+        plan.hold(dz, x_pre, dx, add)
+        plan.add(key + ".bapply", lib.combat_norm_bwd_apply, dz.data_ptr(), x_pre.data_ptr(), _p(add), dx.data_ptr(),
+                 n * p * q, c, p * q if grouped else 0, grouped, ca.data_ptr(), cb.data_ptr(), cc.data_ptr())
+
+
+# --------------------------------------------------------------------------------------------
+# classifiers
+# --------------------------------------------------------------------------------------------
+
+
+class _BN:
+    def __init__(self, eng: "NetEngine", mod: torch.nn.BatchNorm2d, prefix: str):
+        self.prefix, self.C = prefix, mod.num_features
+        self.gamma, self.beta = mod.weight.data, mod.bias.data
+        self.rm, self.rv, self.nbt = mod.running_mean, mod.running_var, mod.num_batches_tracked
+        self.escale = torch.empty(self.C, dtype=f32, device=eng.device)
+        self.eshift = torch.empty(self.C, dtype=f32, device=eng.device)
+
+    def fold(self):
+        ops.bn_eval_fold(self.gamma, self.beta, self.rm, self.rv, self.escale, self.eshift)
+
+    def eval_affine(self) -> Affine:
+        return Affine(self.escale, self.eshift, 0, True, 0.0)
+
+
+class _Blk:
+    pass
+
+
+class PreActEngine(NetEngine):
+    """PreActResNet18 (classifier_models/preact_resnet.py): stem conv, 8 pre-activation blocks,
+    avg-pool + linear + cross-entropy head."""
+
+    def __init__(self, module):
+        super().__init__(module)
+        m = module
+        self.classes = m.linear.out_features
+        self.stem = self._pc(m.conv1.weight.data, 1, 1, 8, dup=True)
+        self.blocks: List[_Blk] = []
+        self.bns: List[_BN] = []
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(m, "layer%d" % li)):
+                e = _Blk()
+                e.prefix = "layer%d.%d." % (li, bi)
+                e.stride, e.cin, e.planes = blk.stride, blk.conv1.in_channels, blk.conv1.out_channels
+                e.bn1, e.bn2 = _BN(self, blk.bn1, e.prefix + "bn1"), _BN(self, blk.bn2, e.prefix + "bn2")
+                e.conv1 = self._pc(blk.conv1.weight.data, blk.stride, 1, e.cin)
+                e.conv2 = self._pc(blk.conv2.weight.data, 1, 1, e.planes)
+                e.sc = self._pc(blk.shortcut[0].weight.data, blk.stride, 0, e.cin) if hasattr(blk, "shortcut") else None
+                self.blocks.append(e)
+                self.bns += [e.bn1, e.bn2]
+        self.lin_w, self.lin_b = m.linear.weight.data, m.linear.bias.data
+
+    def _refresh_extra(self):
+        for bn in self.bns:
+            bn.fold()
+
+    def fold_bn(self):
+        """Running stats changed (a train-mode forward ran): refresh the folded eval scale/shift."""
+        for bn in self.bns:
+            bn.fold()
+
+    # ---- buffers of the head
+    def head_bufs(self, slot: Slot):
+        n = slot.N
+        return dict(
+            logits=slot.buf("logits", (n, self.classes), f32), dlogits=slot.buf("dlogits", (n, self.classes), f32),
+            pooled=slot.buf("pooled", (n, self.lin_w.shape[1]), f32), loss=slot.buf("loss", (1,), f32, zero=True),
+            correct=slot.buf("correct", (2,), torch.int32, zero=True),
+            targets=slot.buf("targets", (n,), torch.int64, zero=True),
+            targets2=slot.buf("targets2", (n,), torch.int64, zero=True))
+
+    def input(self, slot: Slot) -> torch.Tensor:
+        return slot.buf("x", (slot.N, slot.hw, slot.hw, 8))
+
+    def forward_plan(self, slot: Slot, train: bool, loss_weight: float = 1.0, with_targets2: bool = False) -> Plan:
+        key = "fwd.%s.%g.%d" % ("train" if train else "eval", loss_weight, with_targets2)
+        if key in slot.plans:
+            return slot.plans[key]
+        P = Plan("preact." + key)
+        n, hw = slot.N, slot.hw
+        x = self.input(slot)
+        cur = slot.buf("stem", (n, hw, hw, 64))
+        first = self.blocks[0].bn1
+        if train:
+            st = self._conv_norm(P, slot, first.prefix, x, cur, self.stem, groups=1, gamma=first.gamma,
+                                 beta=first.beta, running=(first.rm, first.rv, first.nbt))
+            aff = Affine(st.scale, st.shift, 0, True, 0.0)
+        else:
+            rec_conv(P, "stem", x, cur, self.stem, 0)
+            aff = first.eval_affine()
+        chw = hw
+        for b, blk in enumerate(self.blocks):
+            ohw = chw // blk.stride
+            if blk.sc is not None:
+                resid = slot.buf("b%d.sc" % b, (n, ohw, ohw, blk.planes))
+                rec_conv(P, "b%d.sc" % b, cur, resid, blk.sc, 0, pro=aff)
+            else:
+                resid = cur
+            y1 = slot.buf("b%d.y1" % b, (n, ohw, ohw, blk.planes))
+            out = slot.buf("b%d.out" % b, (n, ohw, ohw, blk.planes))
+            nxt = self.blocks[b + 1].bn1 if b + 1 < len(self.blocks) else None
+            if train:
+                st2 = self._conv_norm(P, slot, blk.bn2.prefix, cur, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
+                                      beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt), pro=aff)
+                aff2 = Affine(st2.scale, st2.shift, 0, True, 0.0)
+                if nxt is not None:
+                    st = self._conv_norm(P, slot, nxt.prefix, y1, out, blk.conv2, groups=1, gamma=nxt.gamma,
+                                         beta=nxt.beta, running=(nxt.rm, nxt.rv, nxt.nbt), pro=aff2, add_post=resid)
+                    aff = Affine(st.scale, st.shift, 0, True, 0.0)
+                else:
+                    rec_conv(P, "b%d.c2" % b, y1, out, blk.conv2, 0, pro=aff2, add_post=resid)
+            else:
+                rec_conv(P, "b%d.c1" % b, cur, y1, blk.conv1, 0, pro=aff)
+                rec_conv(P, "b%d.c2" % b, y1, out, blk.conv2, 0, pro=blk.bn2.eval_affine(), add_post=resid)
+                aff = nxt.eval_affine() if nxt is not None else None
+            cur, chw = out, ohw
+        h = self.head_bufs(slot)
+        P.hold(h)
+        P.add("head", lib.combat_head_fwd, cur.data_ptr(), n, chw, cur.shape[-1], self.lin_w.data_ptr(),
+              self.lin_b.data_ptr(), self.classes, h["targets"].data_ptr(), loss_weight, h["pooled"].data_ptr(),
+              h["logits"].data_ptr(), h["loss"].data_ptr(), h["correct"].data_ptr(),
+              h["targets2"].data_ptr() if with_targets2 else None,
+              h["correct"][1:].data_ptr() if with_targets2 else None)
+        slot.plans[key] = P
+        slot.feat_hw = chw
+        return P
+
+    def _block_io(self, slot: Slot, b: int):
+        xin = slot.bufs["stem"] if b == 0 else slot.bufs["b%d.out" % (b - 1)]
+        return xin, slot.bufs["b%d.y1" % b], slot.bufs["b%d.out" % b]
+
+    def backward_train_plan(self, slot: Slot, loss_weight: float = 1.0) -> Plan:
+        """Backward of a train-mode forward: all parameter gradients (into fp.grad, which the plan
+        zeroes first); no input gradient (Phase C never needs it, train_generator.py:220)."""
+        key = "bwd.train.%g" % loss_weight
+        if key in slot.plans:
+            return slot.plans[key]
+        P = Plan("preact." + key)
+        fp, n = self.fp, slot.N
+        h = self.head_bufs(slot)
+        P.add("zero_grad", lib.combat_memset_zero, fp.grad.data_ptr(), fp.total * 4)
+        feat = slot.bufs["b%d.out" % (len(self.blocks) - 1)]
+        d_out = slot.buf("g.feat", feat.shape)
+        P.add("head_bwd", lib.combat_head_bwd, h["pooled"].data_ptr(), n, slot.feat_hw, feat.shape[-1],
+              self.lin_w.data_ptr(), self.classes, h["logits"].data_ptr(), h["targets"].data_ptr(), loss_weight,
+              h["dlogits"].data_ptr(), d_out.data_ptr(), fp.grad_phys("linear.weight").data_ptr(),
+              fp.grad_phys("linear.bias").data_ptr())
+        for b in reversed(range(len(self.blocks))):
+            blk = self.blocks[b]
+            xin, y1, _ = self._block_io(slot, b)
+            st1, st2 = slot.norm[blk.bn1.prefix], slot.norm[blk.bn2.prefix]
+            aff1 = Affine(st1.scale, st1.shift, 0, True, 0.0)
+            aff2 = Affine(st2.scale, st2.shift, 0, True, 0.0)
+            pre = blk.prefix
+            rec_wgrad(P, "b%d.c2.wgrad" % b, y1, d_out, blk.conv2, fp.grad_phys(pre + "conv2.weight"), aff2)
+            dz2 = slot.buf("g.b%d.dz2" % b, y1.shape)
+            self._dgrad_norm(P, slot, "g." + blk.bn2.prefix, d_out, dz2, blk.conv2, y1, st2, group_stride=0,
+                             slope=0.0, gamma=blk.bn2.gamma, dgamma=fp.grad_phys(pre + "bn2.weight"),
+                             dbeta=fp.grad_phys(pre + "bn2.bias"))
+            dy1 = slot.buf("g.b%d.dy1" % b, y1.shape)
+            self._bwd_apply(P, "g." + blk.bn2.prefix, dz2, y1, dy1, st2)
+            tsc = None
+            if blk.sc is not None:
+                rec_wgrad(P, "b%d.sc.wgrad" % b, xin, d_out, blk.sc, fp.grad_phys(pre + "shortcut.0.weight"), aff1)
+                tsc = slot.buf("g.b%d.tsc" % b, xin.shape)
+                rec_conv(P, "b%d.sc.dgrad" % b, d_out, tsc, blk.sc, 1)
+            rec_wgrad(P, "b%d.c1.wgrad" % b, xin, dy1, blk.conv1, fp.grad_phys(pre + "conv1.weight"), aff1)
+            dz1 = slot.buf("g.b%d.dz1" % b, xin.shape)
+            self._dgrad_norm(P, slot, "g." + blk.bn1.prefix, dy1, dz1, blk.conv1, xin, st1, group_stride=0,
+                             slope=0.0, gamma=blk.bn1.gamma, dgamma=fp.grad_phys(pre + "bn1.weight"),
+                             dbeta=fp.grad_phys(pre + "bn1.bias"), add_pre=tsc)
+            dxin = slot.buf("g.b%d.dx" % b, xin.shape)
+            self._bwd_apply(P, "g." + blk.bn1.prefix, dz1, xin, dxin, st1, add=None if blk.sc is not None else d_out)
+            d_out = dxin
+        rec_wgrad(P, "stem.wgrad", self.input(slot), d_out, self.stem, fp.grad_phys("conv1.weight"))
+        slot.plans[key] = P
+        return P
+
+    def backward_eval_plan(self, slot: Slot, loss_weight: float) -> Plan:
+        """Backward of an eval-mode forward w.r.t. the input image only (Phase G: the classifier
+        and clean-model weight gradients are never consumed, train_generator.py:179,254).
+        Result: slot buffer 'g.img' (bf16 NHWC c8, channels 0..2)."""
+        key = "bwd.eval.%g" % loss_weight
+        if key in slot.plans:
+            return slot.plans[key]
+        P = Plan("preact." + key)
+        n = slot.N
+        h = self.head_bufs(slot)
+        feat = slot.bufs["b%d.out" % (len(self.blocks) - 1)]
+        d_out = slot.buf("g.feat", feat.shape)
+        P.add("head_bwd", lib.combat_head_bwd, None, n, slot.feat_hw, feat.shape[-1], self.lin_w.data_ptr(),
+              self.classes, h["logits"].data_ptr(), h["targets"].data_ptr(), loss_weight, h["dlogits"].data_ptr(),
+              d_out.data_ptr(), None, None)
+        for b in reversed(range(len(self.blocks))):
+            blk = self.blocks[b]
+            xin, y1, _ = self._block_io(slot, b)
+            dy1 = slot.buf("g.b%d.dy1" % b, y1.shape)
+            rec_conv(P, "b%d.c2.dgrad" % b, d_out, dy1, blk.conv2, 1, mask_x=y1, mask=blk.bn2.eval_affine(),
+                     mask_mul_scale=True)
+            tsc = None
+            if blk.sc is not None:
+                tsc = slot.buf("g.b%d.tsc" % b, xin.shape)
+                rec_conv(P, "b%d.sc.dgrad" % b, d_out, tsc, blk.sc, 1)
+            dxin = slot.buf("g.b%d.dx" % b, xin.shape)
+            rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=tsc, mask_x=xin,
+                     mask=blk.bn1.eval_affine(), mask_mul_scale=True, add_post=None if blk.sc is not None else d_out)
+            d_out = dxin
+        gimg = slot.buf("g.img", (n, slot.hw, slot.hw, 8))
+        rec_conv(P, "stem.dgrad", d_out, gimg, self.stem, 1)
+        slot.plans[key] = P
+        return P
+
+
+# --------------------------------------------------------------------------------------------
+# UNet generator
+# --------------------------------------------------------------------------------------------
+
+
+class UnetEngine(NetEngine):
+    """UnetGenerator (networks/models.py:268-341).  Tensors: t[name] = raw conv outputs,
+    up[level] = LeakyReLU(bilinear_up(...)) decoder inputs; InstanceNorm + LeakyReLU live in the
+    prologue of the consuming convolution."""
+
+    LR = 0.2
+
+    def __init__(self, module):
+        super().__init__(module)
+        m = module
+        self.nf = m.nf
+        self.pc: Dict[str, PackedConv] = {}
+        self.bias: Dict[str, torch.Tensor] = {}
+        for name, ci, co, stride, _ in UNET_LAYERS:
+            conv = getattr(m, name)
+            cin_pad = 8 if ci == 0 else conv.in_channels
+            self.pc[name] = self._pc(conv.weight.data, stride, 1, cin_pad, dup=(ci == 0), need_dgrad=(ci != 0))
+            self.bias[name] = conv.bias.data if conv.bias is not None else None
+        self.out_bias8 = torch.zeros(8, dtype=f32, device=self.device)
+
+    def _refresh_extra(self):
+        b = self.bias["upconv0_0"]
+        if b is not None:
+            self.out_bias8[: b.numel()].copy_(b)
+
+    def input(self, slot: Slot) -> torch.Tensor:
+        return slot.buf("x", (slot.N, slot.hw, slot.hw, 8))
+
+    def output(self, slot: Slot) -> torch.Tensor:
+        return slot.buf("noise", (slot.N, slot.hw, slot.hw, 8))
+
+    def _in_aff(self, st: NormState) -> Affine:
+        return Affine(st.scale, st.shift, st.C, True, self.LR)
+
+    def forward_plan(self, slot: Slot) -> Plan:
+        if "fwd" in slot.plans:
+            return slot.plans["fwd"]
+        P = Plan("unet.fwd")
+        n, hw, nf = slot.N, slot.hw, self.nf
+        T = lambda name, s, c: slot.buf("t." + name, (n, s, s, c))
+        x = self.input(slot)
+        h1, h2, h3, h4 = hw // 2, hw // 4, hw // 8, hw // 16
+        pc, bs = self.pc, self.bias
+        t00 = T("conv0_0", h1, nf)
+        rec_conv(P, "conv0_0", x, t00, pc["conv0_0"], 0, bias=bs["conv0_0"])
+        lr_only = Affine(None, None, 0, True, self.LR)
+
+        def cn(name, src, s, c, pro):
+            # no bias here: InstanceNorm removes any per-(image, channel) constant, so
+            # IN(conv(x) + b) == IN(conv(x)) exactly, and leaving b out keeps the stored bf16
+            # tensor better centred (less rounding error amplified by 1/sigma)
+            dst = T(name, s, c)
+            st = self._conv_norm(P, slot, name, src, dst, pc[name], groups=n, pro=pro)
+            return dst, st
+
+        t01, s01 = cn("conv0_1", t00, h1, nf, lr_only)
+        t10, s10 = cn("conv1_0", t01, h2, nf * 2, self._in_aff(s01))
+        t11, s11 = cn("conv1_1", t10, h2, nf * 2, self._in_aff(s10))
+        t20, s20 = cn("conv2_0", t11, h3, nf * 4, self._in_aff(s11))
+        t21, s21 = cn("conv2_1", t20, h3, nf * 4, self._in_aff(s20))
+        t30, s30 = cn("conv3_0", t21, h4, nf * 8, self._in_aff(s21))
+        t31, s31 = cn("conv3_1", t30, h4, nf * 8, self._in_aff(s30))
+
+        def up(level, y, sy, skip, ss, s_in, c):
+            o = slot.buf("up%d" % level, (n, 2 * s_in, 2 * s_in, c))
+            P.hold(y, skip)
+            P.add("up%d" % level, lib.combat_unet_up_fwd, y.data_ptr(), sy.scale.data_ptr(), sy.shift.data_ptr(),
+                  _p(skip), ss.scale.data_ptr() if ss else None, ss.shift.data_ptr() if ss else None, n, s_in, s_in, c,
+                  o.data_ptr())
+            return o
+
+        u3 = up(3, t31, s31, None, None, h4, nf * 8)
+        tu31, su31 = cn("upconv3_1", u3, h3, nf * 8, None)
+        tu30, su30 = cn("upconv3_0", tu31, h3, nf * 4, self._in_aff(su31))
+        u2 = up(2, tu30, su30, t21, s21, h3, nf * 4)
+        tu21, su21 = cn("upconv2_1", u2, h2, nf * 4, None)
+        tu20, su20 = cn("upconv2_0", tu21, h2, nf * 2, self._in_aff(su21))
+        u1 = up(1, tu20, su20, t11, s11, h2, nf * 2)
+        tu11, su11 = cn("upconv1_1", u1, h1, nf * 2, None)
+        tu10, su10 = cn("upconv1_0", tu11, h1, nf, self._in_aff(su11))
+        u0 = up(0, tu10, su10, t01, s01, h1, nf)
+        tu01, su01 = cn("upconv0_1", u0, hw, nf, None)
+        rec_conv(P, "upconv0_0", tu01, self.output(slot), pc["upconv0_0"], 0, pro=self._in_aff(su01),
+                 bias=self.out_bias8, tanh_out=True)
+        slot.plans["fwd"] = P
+        return P
+
+    def backward_plan(self, slot: Slot) -> Plan:
+        """Given slot buffer 'g.z' (gradient w.r.t. the pre-tanh output, bf16 NHWC c8) produce all
+        parameter gradients in fp.grad (zeroed first).  Conv biases that feed an InstanceNorm get
+        an exactly-zero gradient (the norm removes any per-channel constant)."""
+        if "bwd" in slot.plans:
+            return slot.plans["bwd"]
+        P = Plan("unet.bwd")
+        fp, n, hw, nf = self.fp, slot.N, slot.hw, self.nf
+        pc = self.pc
+        t = lambda name: slot.bufs["t." + name]
+        stn = lambda name: slot.norm[name]
+        G = lambda name, like: slot.buf("g." + name, like.shape)
+        P.add("zero_grad", lib.combat_memset_zero, fp.grad.data_ptr(), fp.total * 4)
+        gz = slot.buf("g.z", (n, hw, hw, 8))
+        P.add("db.upconv0_0", lib.combat_colsum, gz.data_ptr(), n * hw * hw, 8, 3,
+              fp.grad_phys("upconv0_0.bias").data_ptr())
+
+        def through_norm(name, dy, pcv, src_name, add_pre=None):
+            """dy = gradient w.r.t. raw output of conv `pcv` whose input is LR(IN(t[src_name])).
+            wgrad of pcv, then gradient w.r.t. t[src_name] (returned)."""
+            src, st = t(src_name), stn(src_name)
+            rec_wgrad(P, name + ".wgrad", src, dy, pcv, fp.grad_phys(name + ".weight"), self._in_aff(st))
+            dz = G(src_name + ".dz", src)
+            self._dgrad_norm(P, slot, "g." + src_name, dy, dz, pcv, src, st, group_stride=st.C, slope=self.LR,
+                             add_pre=add_pre)
+            dx = G(src_name + ".dx", src)
+            self._bwd_apply(P, "g." + src_name, dz, src, dx, st)
+            return dx
+
+        def through_up(name, dy, pcv, level, y_name):
+            """dy = gradient w.r.t. raw output of conv `pcv` whose input is up[level].  Returns
+            (du, d_y): du = gradient w.r.t. the pre-upsample sum, d_y = gradient w.r.t. t[y_name]."""
+            u = slot.bufs["up%d" % level]
+            rec_wgrad(P, name + ".wgrad", u, dy, pcv, fp.grad_phys(name + ".weight"), None)
+            du_full = G("up%d.d" % level, u)
+            rec_conv(P, name + ".dgrad", dy, du_full, pcv, 1)
+            y, st = t(y_name), stn(y_name)
+            du = G("u%d" % level, y)
+            P.add("up%d.bwd" % level, lib.combat_unet_up_bwd, du_full.data_ptr(), u.data_ptr(), n, y.shape[1],
+                  y.shape[2], y.shape[3], du.data_ptr())
+            part, rpg = self._stats_bwd(P, slot, "g." + y_name, du, y, st)
+            self._bwd_finalize(P, "g." + y_name, part, rpg, y.shape[1] * y.shape[2], st, None, None, None)
+            dy_out = G(y_name + ".dx", y)
+            self._bwd_apply(P, "g." + y_name, du, y, dy_out, st)
+            return du, dy_out
+
+        d = through_norm("upconv0_0", gz, pc["upconv0_0"], "upconv0_1")
+        du0, d = through_up("upconv0_1", d, pc["upconv0_1"], 0, "upconv1_0")
+        d = through_norm("upconv1_0", d, pc["upconv1_0"], "upconv1_1")
+        du1, d = through_up("upconv1_1", d, pc["upconv1_1"], 1, "upconv2_0")
+        d = through_norm("upconv2_0", d, pc["upconv2_0"], "upconv2_1")
+        du2, d = through_up("upconv2_1", d, pc["upconv2_1"], 2, "upconv3_0")
+        d = through_norm("upconv3_0", d, pc["upconv3_0"], "upconv3_1")
+        _, d = through_up("upconv3_1", d, pc["upconv3_1"], 3, "conv3_1")
+        d = through_norm("conv3_1", d, pc["conv3_1"], "conv3_0")
+        d = through_norm("conv3_0", d, pc["conv3_0"], "conv2_1", add_pre=du2)
+        d = through_norm("conv2_1", d, pc["conv2_1"], "conv2_0")
+        d = through_norm("conv2_0", d, pc["conv2_0"], "conv1_1", add_pre=du1)
+        d = through_norm("conv1_1", d, pc["conv1_1"], "conv1_0")
+        d = through_norm("conv1_0", d, pc["conv1_0"], "conv0_1", add_pre=du0)
+        # conv0_1 reads LeakyReLU(conv0_0 output): no norm in between
+        t00 = t("conv0_0")
+        lr_only = Affine(None, None, 0, True, self.LR)
+        rec_wgrad(P, "conv0_1.wgrad", t00, d, pc["conv0_1"], fp.grad_phys("conv0_1.weight"), lr_only)
+        d00 = G("conv0_0.dx", t00)
+        rec_conv(P, "conv0_1.dgrad", d, d00, pc["conv0_1"], 1, mask_x=t00, mask=Affine(None, None, 0, True, self.LR))
+        P.add("db.conv0_0", lib.combat_colsum, d00.data_ptr(), d00.numel() // d00.shape[-1], d00.shape[-1],
+              d00.shape[-1], fp.grad_phys("conv0_0.bias").data_ptr())
+        rec_wgrad(P, "conv0_0.wgrad", self.input(slot), d00, pc["conv0_0"], fp.grad_phys("conv0_0.weight"))
+        slot.plans["bwd"] = P
+        return P
+
+
+# --------------------------------------------------------------------------------------------
+# Frequency detector (metric only)
+# --------------------------------------------------------------------------------------------
+
+
+class FreqEngine(NetEngine):
+    """FrequencyModel (defenses/frequency_based/model.py:8-52) in eval mode: 6 x
+    (conv+bias -> ELU -> BatchNorm(running stats)), 2x2 max-pool after every second, Linear."""
+
+    def __init__(self, module):
+        super().__init__(module)
+        m = module
+        self.layers = []
+        cin = 8
+        for i, w in enumerate(m.WIDTHS, start=1):
+            conv, bn = getattr(m, "conv%d" % i), getattr(m, "bn%d" % i)
+            self.layers.append((self._pc(conv.weight.data, 1, 1, cin, dup=(i == 1), need_dgrad=False), conv.bias.data,
+                                _BN(self, bn, "bn%d" % i)))
+            cin = w
+        self.lin_w, self.lin_b = m.linear6.weight.data, m.linear6.bias.data
+        self.classes = m.linear6.out_features
+
+    def _refresh_extra(self):
+        for _, _, bn in self.layers:
+            bn.fold()
+
+    def input(self, slot: Slot) -> torch.Tensor:
+        return slot.buf("x", (slot.N, slot.hw, slot.hw, 8))
+
+    def forward_plan(self, slot: Slot) -> Plan:
+        if "fwd" in slot.plans:
+            return slot.plans["fwd"]
+        P = Plan("freq.fwd")
+        n, s = slot.N, slot.hw
+        cur = self.input(slot)
+        for i, (pc, bias, bn) in enumerate(self.layers, start=1):
+            raw = slot.buf("c%d" % i, (n, s, s, pc.K))
+            rec_conv(P, "conv%d" % i, cur, raw, pc, 0, bias=bias)
+            act = slot.buf("a%d" % i, (n, s, s, pc.K))
+            P.add("elu_bn%d" % i, lib.combat_elu_affine, raw.data_ptr(), n * s * s, pc.K, bn.escale.data_ptr(),
+                  bn.eshift.data_ptr(), act.data_ptr())
+            cur = act
+            if i % 2 == 0:
+                pooled = slot.buf("p%d" % i, (n, s // 2, s // 2, pc.K))
+                P.add("pool%d" % i, lib.combat_maxpool2, cur.data_ptr(), n, s, s, pc.K, pooled.data_ptr())
+                cur, s = pooled, s // 2
+        logits = slot.buf("logits", (n, self.classes), f32)
+        P.add("linear", lib.combat_linear_nhwc, cur.data_ptr(), n, s, s, cur.shape[-1], self.lin_w.data_ptr(),
+              self.lin_b.data_ptr(), self.classes, logits.data_ptr())
+        slot.plans["fwd"] = P
+        return P
+
+
+# --------------------------------------------------------------------------------------------
+# drop-in module(x) with autograd (reference call signature; not the fast path)
+# --------------------------------------------------------------------------------------------
+
+ENGINES = {"preact_resnet18": PreActEngine, "unet": UnetEngine, "freq": FreqEngine}
+
+
+def build_engine(module) -> NetEngine:
+    cls = ENGINES.get(module.arch)
+    if cls is None:
+        raise NotImplementedError("no HIP engine for architecture %r yet" % module.arch)
+    return cls(module)
+
+
+def _images_to_c8(x: torch.Tensor, dst: torch.Tensor) -> None:
+    ops.image_to_c8(x.contiguous().float(), dst)
+
+
+class _ClassifierFn(torch.autograd.Function):
+    """logits = netC(x) through the HIP plans.  Backward supports the two uses the reference
+    makes of a classifier: train mode -> parameter gradients; eval mode -> input gradient."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng: PreActEngine = module._net_engine()
+        eng.refresh()
+        n, _, hw, _ = x.shape
+        train = module.training
+        slot = eng.slot("module.train" if train else "module.eval", n, hw)
+        _images_to_c8(x, eng.input(slot))
+        eng.forward_plan(slot, train).run()
+        if train:
+            eng.fold_bn()
+        ctx.module, ctx.slot, ctx.train = module, slot, train
+        return eng.head_bufs(slot)["logits"].clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        raise NotImplementedError(
+            "differentiate through combat_amd.step.AlternatedStep (fused loss heads); module(x) is inference-only")
+
+
+class _GeneratorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng: UnetEngine = module._net_engine()
+        eng.refresh()
+        n, _, hw, _ = x.shape
+        if n == 0:
+            return x.new_zeros(x.shape)
+        slot = eng.slot("module", n, hw)
+        _images_to_c8(x, eng.input(slot))
+        eng.forward_plan(slot).run()
+        out = torch.empty(n, 3, hw, hw, dtype=f32, device=x.device)
+        ops.nhwc_to_nchw_f32(eng.output(slot), 3, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError(
+            "differentiate through combat_amd.step.AlternatedStep; module(x) is inference-only")
+
+
+def module_forward(module, x: torch.Tensor) -> torch.Tensor:
+    """The reference's `module(x)` call signature (float32 NCHW in, float32 out) on the HIP path."""
+    if x.device.type != "cuda":
+        raise CombatHipError("combat_amd modules run on the GPU only; got a %s tensor" % x.device)
+    params = tuple(module.parameters())
+    if module.arch == "unet":
+        return _GeneratorFn.apply(module, x, *params)
+    if module.arch in ("preact_resnet18", "resnet18"):
+        return _ClassifierFn.apply(module, x, *params)
+    if module.arch == "freq":
+        eng = module._net_engine()
+        eng.refresh()
+        n, _, hw, _ = x.shape
+        slot = eng.slot("module", n, hw)
+        ops.image_to_c8(x.contiguous().float(), eng.input(slot))  # hi/lo split keeps the DCT's dynamic range
+        eng.forward_plan(slot).run()
+        return slot.bufs["logits"].clone()
+    raise NotImplementedError(module.arch)

@@ -90,7 +90,7 @@ class PackedConv:
 
 def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = None, bias=None, add_pre=None,
               mask_x=None, mask: Optional[Affine] = None, mask_mul_scale=False, add_post=None, tanh_out=False,
-              stats_kind=0, stats=None, xh_scale=None, xh_shift=None, tile=0) -> ConvArgs:
+              stats_kind=0, stats=None, xh_mean=None, xh_rstd=None, tile=0) -> ConvArgs:
     a = ConvArgs()
     a.N, a.H, a.W, a.C = src.shape
     _, a.P, a.Q, a.K = dst.shape
@@ -111,10 +111,10 @@ def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = No
     a.mask_mul_scale = int(mask_mul_scale)
     a.tanh_out = int(tanh_out)
     a.stats_kind, a.stats = stats_kind, _p(stats)
-    a.xh_scale, a.xh_shift = _p(xh_scale), _p(xh_shift)
+    a.xh_mean, a.xh_rstd = _p(xh_mean), _p(xh_rstd)
     a.tile = tile
     # the struct holds raw pointers: keep every tensor alive as long as the struct is
-    a._keepalive = (src, dst, pc, pro, bias, add_pre, mask_x, mask, add_post, stats, xh_scale, xh_shift)
+    a._keepalive = (src, dst, pc, pro, bias, add_pre, mask_x, mask, add_post, stats, xh_mean, xh_rstd)
     return a
 
 
@@ -178,9 +178,9 @@ def group_stats(x, parts, rows_per_part, partials) -> None:
           "combat_group_stats", "parts=%d rows=%d C=%d" % (parts, rows_per_part, x.shape[-1]))
 
 
-def group_stats_bwd(dz, x, parts, rows_per_part, parts_per_image, xh_scale, xh_shift, partials) -> None:
+def group_stats_bwd(dz, x, parts, rows_per_part, parts_per_image, xh_mean, xh_rstd, partials) -> None:
     check(lib.combat_group_stats_bwd(dz.data_ptr(), x.data_ptr(), parts, rows_per_part, x.shape[-1], parts_per_image,
-                                     xh_scale.data_ptr(), xh_shift.data_ptr(), partials.data_ptr(), _stream()),
+                                     xh_mean.data_ptr(), xh_rstd.data_ptr(), partials.data_ptr(), _stream()),
           "combat_group_stats_bwd", "parts=%d rows=%d C=%d" % (parts, rows_per_part, x.shape[-1]))
 
 
@@ -211,10 +211,10 @@ def trigger_fwd(x, noise, p_mat, k1, noise_rate, out, out_c8=None, mse_partial=N
           "combat_trigger_fwd", str(tuple(x.shape)))
 
 
-def trigger_bwd(x, noise, p_mat, k1, noise_rate, d_out, out, l2_scale, d_noise) -> None:
+def trigger_bwd(x, noise, p_mat, k1, noise_rate, d_out, out, l2_scale, d_noise, pre_tanh=False) -> None:
     n, _, hw, _ = x.shape
     check(lib.combat_trigger_bwd(x.data_ptr(), noise.data_ptr(), p_mat.data_ptr(), k1.data_ptr(), noise_rate, n, hw,
-                                 _p(d_out), _p(out), l2_scale, d_noise.data_ptr(), _stream()),
+                                 _p(d_out), _p(out), l2_scale, int(pre_tanh), d_noise.data_ptr(), _stream()),
           "combat_trigger_bwd", str(tuple(x.shape)))
 
 
@@ -223,8 +223,9 @@ def augment_fwd(x, n, hw, out_c8, params=None, index=None, out_f32=None) -> None
                                  _stream()), "combat_augment_fwd", "n=%d hw=%d" % (n, hw))
 
 
-def augment_bwd(d_c8, n, hw, d_x, params=None) -> None:
-    check(lib.combat_augment_bwd(d_c8.data_ptr(), d_c8.shape[-1], _p(params), n, hw, d_x.data_ptr(), _stream()),
+def augment_bwd(d_c8, n, hw, d_x, params=None, accumulate=False) -> None:
+    check(lib.combat_augment_bwd(d_c8.data_ptr(), d_c8.shape[-1], _p(params), n, hw, d_x.data_ptr(),
+                                 int(accumulate), _stream()),
           "combat_augment_bwd", "n=%d hw=%d" % (n, hw))
 
 

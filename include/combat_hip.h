@@ -85,11 +85,11 @@ typedef struct combat_conv_args {
     const void *add_post;        /* v += add_post[m][n]  bf16, dst-shaped         (may be NULL) */
     int32_t tanh_out;            /* v = tanh(v) */
     /* statistics of the stored (bf16-rounded) values, per granule of `stats_granule` rows:
-       stats_kind 1: (sum v, sum v*v);  2: (sum v, sum v*xh) with xh = mask_x*xh_scale + xh_shift.
+       stats_kind 1: (sum v, sum v*v);  2: (sum v, sum v*xh) with xh = (mask_x - xh_mean)*xh_rstd.
        layout fp32 [ceil(M/granule)][2][K]; granule is fixed by the tile (query below). */
     int32_t stats_kind;
     float *stats;
-    const float *xh_scale, *xh_shift;       /* group stride = mask_group_stride */
+    const float *xh_mean, *xh_rstd;         /* group stride = mask_group_stride */
     int32_t tile;                /* 0 = auto; else a COMBAT_TILE_* value */
 } combat_conv_args;
 
@@ -184,9 +184,9 @@ int combat_norm_bwd_apply(const void *dz, const void *x, const void *add, void *
                           const float *ca, const float *cb, const float *cc, void *stream);
 
 /* per-part (sum dz, sum dz*xhat), same layout as combat_group_stats:
- * xhat = x*xh_scale[i][c] + xh_shift[i][c], i = part / parts_per_image (0 => i = 0) */
+ * xhat = (x - xh_mean[i][c]) * xh_rstd[i][c], i = part / parts_per_image (0 => i = 0) */
 int combat_group_stats_bwd(const void *dz, const void *x, int32_t groups, int32_t rows_per_group,
-                           int32_t C, int32_t parts_per_image, const float *xh_scale, const float *xh_shift,
+                           int32_t C, int32_t parts_per_image, const float *xh_mean, const float *xh_rstd,
                            float *partials, void *stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -211,13 +211,15 @@ int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N, int32_t H,
  * noise: bf16 NHWC c8 (channels 0..2) -- the generator's tanh output; x, out: fp32 NCHW [n][3][hw][hw].
  * out_c8 (may be NULL): the same result as the NHWC c8 hi/lo image the classifier stem reads.
  * mse_partial (may be NULL): fp32 [n] per-image sum (out - x)^2 (MSELoss, train_generator.py:234).
- * Backward: d_noise (bf16 NHWC c8) from d_out (fp32 NCHW) [+ 2*l2_scale*(out-x) MSE term].
+ * Backward: d_noise (bf16 NHWC c8) from d_out (fp32 NCHW) [+ 2*l2_scale*(out-x) MSE term];
+ * pre_tanh != 0 multiplies by (1 - noise^2), i.e. returns the gradient w.r.t. the generator's
+ * pre-tanh output (networks/models.py:340).
  * ------------------------------------------------------------------------------------------ */
 int combat_trigger_fwd(const float *x, const void *noise, const float *P, const float *k1, float noise_rate,
                        int32_t n, int32_t hw, float *out, void *out_c8, float *mse_partial, void *stream);
 int combat_trigger_bwd(const float *x, const void *noise, const float *P, const float *k1, float noise_rate,
                        int32_t n, int32_t hw, const float *d_out, const float *out, float l2_scale,
-                       void *d_noise, void *stream);
+                       int32_t pre_tanh, void *d_noise, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * PostTensorTransform (utils/dataloader.py:45-60): per-sample crop(pad, integer offset) ->
@@ -225,12 +227,13 @@ int combat_trigger_bwd(const float *x, const void *noise, const float *P, const 
  * params: fp32 [n][4] = (crop_dx - pad, crop_dy - pad, angle_radians, flip) ; NULL = identity.
  * src_index (may be NULL): int32 [n] gather of the batch (train_generator.py:195 reorder).
  * x fp32 NCHW [*][3][hw][hw] -> out_c8 bf16 NHWC c8 hi/lo (and out_f32 NCHW if not NULL).
- * Backward: d_c8 bf16 NHWC c8 (channels 0..2 = gradient w.r.t. the image) -> d_x fp32 NCHW.
+ * Backward: d_c8 bf16 NHWC c8 (channels 0..2 = gradient w.r.t. the image) -> d_x fp32 NCHW
+ * (overwritten, or added to when accumulate != 0: two classifiers read the same image).
  * ------------------------------------------------------------------------------------------ */
 int combat_augment_fwd(const float *x, const int32_t *src_index, const float *params, int32_t n, int32_t hw,
                        void *out_c8, float *out_f32, void *stream);
 int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const float *params, int32_t n, int32_t hw,
-                       float *d_x, void *stream);
+                       float *d_x, int32_t accumulate, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Classifier head: avg_pool(4) -> flatten -> Linear -> CrossEntropyLoss(mean)
@@ -272,6 +275,8 @@ int combat_nhwc_to_nchw_f32(const void *x, int32_t n, int32_t h, int32_t w, int3
 /* fp32 NCHW -> bf16 NHWC with C padded to a multiple of 8 */
 int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t C, void *out,
                              void *stream);
+/* hipMemsetAsync(ptr, 0, bytes): gradient buffers are accumulated into and must start at zero */
+int combat_memset_zero(void *ptr, int64_t bytes, void *stream);
 /* column sums of a bf16 [rows][C] tensor into fp32 out[c_out] (overwritten): conv bias gradient */
 int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream);
 /* 2x2 max pool, bf16 NHWC (frequency model.py:21,32,43) */

@@ -189,21 +189,20 @@ def test_conv_dgrad_epilogue_mask_stats(ops):
     sh = torch.randn(c, generator=g(36)) * 0.3
     mean = torch.randn(c, generator=g(37)) * 0.1
     rstd = torch.rand(c, generator=g(38)) + 0.5
-    xh_s, xh_b = rstd, -mean * rstd
     da = torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1) + rb(extra)
     msk = ((rb(xpre) * sc[None, :, None, None] + sh[None, :, None, None]) > 0).float()
     dz_ref = da * msk
     dz = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
     a = ops.conv_args(nhwc(dy), dz, pc, 1, add_pre=nhwc(extra), mask_x=nhwc(xpre),
-                      mask=ops.Affine(dev(sc), dev(sh), 0, True, 0.0), stats_kind=2, xh_scale=dev(xh_s),
-                      xh_shift=dev(xh_b))
+                      mask=ops.Affine(dev(sc), dev(sh), 0, True, 0.0), stats_kind=2, xh_mean=dev(mean),
+                      xh_rstd=dev(rstd))
     tile, gran = ops.conv_tile_granule(a)
     stats = torch.zeros((n * hw * hw + gran - 1) // gran, 2, c, device="cuda")
     a.stats = stats.data_ptr()
     ops.conv_launch(a)
     assert rel_l2(nchw(dz), dz_ref) < 4e-3
     dzr = nchw(dz)
-    xhat = rb(xpre) * xh_s[None, :, None, None] + xh_b[None, :, None, None]
+    xhat = (rb(xpre) - mean[None, :, None, None]) * rstd[None, :, None, None]
     s = stats.sum(0).cpu()
     assert rel_l2(s[0], dzr.sum((0, 2, 3))) < 1e-4
     assert rel_l2(s[1], (dzr * xhat).sum((0, 2, 3))) < 1e-4
@@ -289,8 +288,7 @@ def test_instance_norm_small_groups_and_backward(ops):
     y = F.instance_norm(xr.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
     assert rel_l2(xr.detach() * scale.cpu()[:, None] + shift.cpu()[:, None], y) < 1e-5
     y.backward(rb(dy))
-    xh_shift = -mean * rstd
-    ops.group_stats_bwd(dyb, xb, n, hw2, 1, rstd, xh_shift, partials)
+    ops.group_stats_bwd(dyb, xb, n, hw2, 1, mean, rstd, partials)
     ca, cb, cc = (torch.empty(n, c, device="cuda") for _ in range(3))
     ops.norm_bwd_finalize(partials, n, 1, c, hw2, gamma=None, mean=mean, rstd=rstd, ca=ca, cb=cb, cc=cc)
     dx = torch.empty(n, hw2, c, dtype=bf16, device="cuda")
@@ -309,7 +307,7 @@ def test_batchnorm_backward_coefficients(ops):
     ops.group_stats(xb, parts, gran, partials)
     mean, rstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
     ops.norm_finalize(partials, 1, parts, c, rows, mean=mean, rstd=rstd)
-    ops.group_stats_bwd(dzb, xb, parts, gran, 0, rstd, -mean * rstd, partials)
+    ops.group_stats_bwd(dzb, xb, parts, gran, 0, mean, rstd, partials)
     ca, cb, cc, dg, db = (torch.empty(c, device="cuda") for _ in range(5))
     ops.norm_bwd_finalize(partials, 1, parts, c, rows, gamma=dev(gamma), mean=mean, rstd=rstd, ca=ca, cb=cb, cc=cc,
                           dgamma=dg, dbeta=db)
