@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Throughput of COMBAT's alternated generator+surrogate step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (train_generator.py:170-290: Phase C + Phase G, both SGD
+updates, and for N > 1 both gradient all-reduces) over one synthetic CIFAR-10-shaped batch of 128
+images per GPU that is already resident in HBM.  Prints ONE JSON line on rank 0 (contract in the
+task statement): whole-job images/sec, plus
+
+  roofline      the dominant kernel (the conv gather-GEMM instantiation with the most device time):
+                algorithmic FLOPs of its launches / their HIP-event durations, measured in a second,
+                instrumented replay of the same K steps (events on the launch stream), against the
+                2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline  the CPU oracle (oracle/combat_oracle.py, the fp32 restatement of the reference step,
+                as written incl. its discarded work) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "images/sec per alternated generator+surrogate step, CIFAR-10 bs=128, 1/2/4/8 GPU"
+PEAK_BF16_TFLOPS = 2500.0
+TILE_NAMES = {1: "conv_gemm_kernel<128,128>", 2: "conv_gemm_kernel<128,64>", 3: "conv_gemm_kernel<64,64>",
+              4: "conv_gemm_kernel<128,16>", 5: "conv_gemm_kernel<64,128>"}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", 0)) == 0:
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+class Opt:
+    """config.py defaults of the reference for `--dataset cifar10 --pc 0.5 --noise_rate 0.08`."""
+    dataset = "cifar10"
+    input_height = input_width = 32
+    input_channel, num_classes, bs = 3, 10, 128
+    noise_rate, ratio, kernel_size, sigma = 0.08, 0.65, 3, (0.1, 1.0)
+    pc, target_label, attack_mode = 0.5, 0, "all2one"
+    L2_weight, clean_model_weight, lr_C, lr_G = 0.02, 0.8, 1e-2, 1e-2
+    post_transform_option, random_crop, random_rotation = "use", 5, 10
+
+
+def synth_batches(n_batches, bs, rank, device):
+    """uint8 pixels -> ToTensor + Normalize(0.5, 0.5); labels uniform."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    out = []
+    for _ in range(n_batches):
+        u8 = torch.randint(0, 256, (bs, 3, 32, 32), generator=g, dtype=torch.uint8)
+        x = ((u8.float() / 255) - 0.5) / 0.5
+        t = torch.randint(0, 10, (bs,), generator=g)
+        out.append((x.to(device), t))
+    return out
+
+
+def build_nets(device):
+    from combat_amd import nets
+    torch.manual_seed(0)
+    netc = nets.PreActResNet18()
+    torch.manual_seed(1)
+    clean = nets.PreActResNet18().eval()
+    torch.manual_seed(2)
+    netg = nets.UnetGenerator(None)
+    torch.manual_seed(3)
+    netf = nets.FrequencyModel(2, 3, 32).eval()   # shipped detector weights do not travel: default init
+    return netc.to(device), netg.to(device), clean.to(device), netf.to(device)
+
+
+def conv_flops(a):
+    """Algorithmic FLOPs of one conv launch: 2 * output pixels of the convolution * Cout * Cin * taps
+    with the REAL channel counts (padding channels and the masked taps of a strided dgrad are not work)."""
+    pc = a._keepalive[2]
+    pix = a.N * a.P * a.Q if a.mode == 0 else a.N * a.H * a.W
+    return 2.0 * pix * pc.K * pc.c_real * pc.taps
+
+
+def roofline_from(prof):
+    from combat_amd._lib import lib
+    import ctypes
+    groups = {}
+    for what, a, e0, e1 in prof:
+        tile = lib.combat_conv_pick_tile(ctypes.byref(a))
+        g = groups.setdefault(tile, [0.0, 0.0, 0])
+        g[0] += conv_flops(a)
+        g[1] += e0.elapsed_time(e1) * 1e-3
+        g[2] += 1
+    tile, (fl, sec, cnt) = max(groups.items(), key=lambda kv: kv[1][1])
+    achieved = fl / sec / 1e12
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        "kernel": TILE_NAMES.get(tile, str(tile)), "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
+        "gflop_per_launch": round(fl / cnt / 1e9, 3),
+        "all_conv_tiles": {TILE_NAMES.get(t, str(t)): {"launches": c, "avg_us": round(s / c * 1e6, 2),
+                                                      "tflops": round(f / s / 1e12, 1)}
+                           for t, (f, s, c) in sorted(groups.items())},
+    }
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle's step, as the reference writes it (loss.backward() into every leaf, all five
+    forwards building graphs), fp32, anomaly detection off, on this host's cores."""
+    from combat_amd import nets
+    from oracle import combat_oracle as O
+    # the GPU box gives one GPU a share of 16 host cores (os.cpu_count() reports the whole host):
+    # use the affinity mask, capped at that share, so the CPU leg is not oversubscribed
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    threads = int(os.environ.get("COMBAT_CPU_THREADS", min(cores, 16)))
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    netc = {k: v.clone() for k, v in nets.PreActResNet18().state_dict().items()}
+    torch.manual_seed(1)
+    clean = {k: v.clone() for k, v in nets.PreActResNet18().state_dict().items()}
+    torch.manual_seed(2)
+    netg = {k: v.clone() for k, v in nets.UnetGenerator(None).state_dict().items()}
+    torch.manual_seed(3)
+    netf = {k: v.clone() for k, v in nets.FrequencyModel(2, 3, 32).state_dict().items()}
+    bufs_c, bufs_g = [None] * len(O.trainable_names(netc)), [None] * len(O.trainable_names(netg))
+    g = torch.Generator().manual_seed(1234)
+    bs = 128
+    x = ((torch.randint(0, 256, (bs, 3, 32, 32), generator=g, dtype=torch.uint8).float() / 255) - 0.5) / 0.5
+    t = torch.randint(0, 10, (bs,), generator=g)
+    rng = np.random.default_rng(0)
+
+    def aug():
+        return O.AugParams(rng.integers(0, 11, bs).astype(np.int32), rng.integers(0, 11, bs).astype(np.int32),
+                           np.where(rng.random(bs) < 0.5, rng.uniform(-10, 10, bs), 0).astype(np.float32),
+                           (rng.random(bs) < 0.5).astype(np.int32))
+
+    def one():
+        n_trg = int((t == 0).sum())
+        rnd = O.StepRandomness(int(np.sum(rng.random(n_trg) < 0.5)), 0.5, 0.6, [aug() for _ in range(5)])
+        O.alternated_step(netc, netg, clean, netf, bufs_c, bufs_g, x, t, rnd, O.StepConfig(), as_written=True)
+
+    log("cpu_baseline: %d threads, warm-up step" % threads)
+    one()  # warm-up (allocator, MKL-DNN primitive caches)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        one()
+        steps += 1
+        el = time.perf_counter() - t0
+        log("cpu_baseline: step %d done, %.1f s" % (steps, el))
+        if el > seconds_budget or steps >= 8:
+            break
+    return {"value": round(bs * steps / el, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "%d alternated steps of 128 images after 1 warm-up (%.1f s), fp32 torch-CPU oracle of the "
+                      "reference step as written, set_detect_anomaly off" % (steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+        pg = torch.distributed.group.WORLD
+
+    from combat_amd import step as step_mod
+    opt = Opt()
+    np.random.seed(rank)
+    import random
+    random.seed(rank)
+    torch.manual_seed(100 + rank)
+    netc, netg, clean, netf = build_nets(device)
+    if world > 1:   # identical replicas: rank 0's parameters everywhere
+        for m in (netc, netg, clean, netf):
+            for p in list(m.parameters()) + list(m.buffers()):
+                torch.distributed.broadcast(p.data, 0)
+    st = step_mod.AlternatedStep(netc, netg, clean, netf, opt, process_group=pg)
+    batches = synth_batches(8, opt.bs, rank, device)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    log("setup done; %d warm-up steps" % args.warmup)
+    for i in range(args.warmup):
+        x, t = batches[i % len(batches)]
+        st.run(x, t)
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    sync()
+    log("warm-up done; timing %d steps" % args.steps)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        x, t = batches[i % len(batches)]
+        st.run(x, t)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt)
+    log("timed region: %.3f s (%.3f ms/step)" % (elapsed, elapsed / args.steps * 1e3))
+    metrics = st.read_metrics()
+    finite = all(np.isfinite(v) for v in metrics.values())
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        prof = []
+        for i in range(args.steps):
+            x, t = batches[i % len(batches)]
+            st.run(x, t, prof=prof)
+        torch.cuda.synchronize()
+        roof = roofline_from(prof)
+        log("instrumented replay done: %s %.1f TFLOP/s" % (roof["kernel"], roof["achieved"]))
+    if world > 1:
+        torch.distributed.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": METRIC, "value": round(opt.bs * world * args.steps / elapsed, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "train_generator.py --dataset cifar10 --pc 0.5 --noise_rate 0.08: alternated "
+                                   "PreActResNet18 surrogate + UNet generator step (Phase C + Phase G, both "
+                                   "Nesterov-SGD updates), bs=128 per GPU, on-device augmentation on",
+                       "per_gpu_batch": opt.bs, "global_batch": opt.bs * world,
+                       "parallelism": "dp%d (RCCL all-reduce of netC grads in Phase C, netG grads in Phase G)" % world,
+                       "gflop_per_image_algorithmic": 11.67, "losses_finite": finite},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,10 +43,20 @@ class Plan:
     def hold(self, *objs) -> None:
         self._keep.extend(objs)
 
-    def run(self) -> None:
-        st = torch.cuda.current_stream().cuda_stream
+    def run(self, prof: Optional[list] = None) -> None:
+        """Replay.  `prof` (a list) switches on per-launch HIP-event bracketing of the convolution
+        kernels on the launch stream: it receives (plan/what, ConvArgs, start_event, end_event)."""
+        stream = torch.cuda.current_stream()
+        st = stream.cuda_stream
         for cfunc, args, what in self.calls:
-            rc = cfunc(*args, st)
+            if prof is not None and cfunc is lib.combat_conv_gemm:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                rc = cfunc(*args, st)
+                e1.record(stream)
+                prof.append((self.name + "/" + what, args[0]._obj, e0, e1))
+            else:
+                rc = cfunc(*args, st)
             if rc:
                 kind = {-1: "invalid shape/argument", -2: "HIP launch failed"}.get(rc, "status %d" % rc)
                 raise CombatHipError("%s/%s: %s" % (self.name, what, kind))

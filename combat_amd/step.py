@@ -150,7 +150,7 @@ class AlternatedStep:
 
     # ------------------------------------------------------------------ one step
     def run(self, inputs: torch.Tensor, targets_cpu: torch.Tensor, rnd: Optional[StepRandomness] = None,
-            lr_c: Optional[float] = None, lr_g: Optional[float] = None) -> None:
+            lr_c: Optional[float] = None, lr_g: Optional[float] = None, prof: Optional[list] = None) -> None:
         """inputs: float32 [B,3,H,W] (device or pinned host); targets_cpu: int64 [B] on the host,
         as the DataLoader yields them (train_generator.py:170-171)."""
         opt = self.opt
@@ -209,51 +209,51 @@ class AlternatedStep:
             sS, plan_small, tochange = self._small(nbk)
             ops.check(lib.combat_augment_fwd(x_ptr, self.tab_i[0].data_ptr(), None, nbk, hw, eG.input(sS).data_ptr(),
                                              tochange.data_ptr(), st), "gather poisoned")
-            plan_small.run()
+            plan_small.run(prof)
             ops.check(lib.combat_trigger_fwd(tochange.data_ptr(), eG.output(sS).data_ptr(), P_, k1c, rate, nb, hw,
                                              self.cat_src[n:].data_ptr(), None, None, st), "trigger C")
         ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(), aug_ptr[0], n, hw,
                                          eC.input(self.sC_train).data_ptr(), None, st), "augment 0")
-        pl["C_train_f"].run()
-        pl["C_train_b"].run()
+        pl["C_train_f"].run(prof)
+        pl["C_train_b"].run(prof)
         self._allreduce(eC)
         eC.fp.sgd_step(float(lr_c if lr_c is not None else opt.lr_C), grad_scale=1.0 / self.world)
         eC.mark_weights_dirty()
         eC.refresh()                       # re-pack bf16 operands, fold the new running stats
         ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[1], n, hw, eK.input(self.sK_clean).data_ptr(), None, st),
                   "augment 1")
-        pl["K_clean_f"].run()              # :214 metric only
+        pl["K_clean_f"].run(prof)              # :214 metric only
 
         # ================= Phase G (train_generator.py:216-255) =================
         ops.check(lib.combat_image_to_c8(x_ptr, n, hw, eG.input(self.sG).data_ptr(), st), "c8 G")
-        pl["G_f"].run()
+        pl["G_f"].run(prof)
         noise = eG.output(self.sG)
         ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.bd.data_ptr(), None,
                                          self.mse.data_ptr(), st), "trigger G")
         bd_ptr = self.bd.data_ptr()
         ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, eC.input(self.sC_clean).data_ptr(), None, st),
                   "augment 2")
-        pl["C_clean_f"].run()              # :227 metric only
+        pl["C_clean_f"].run(prof)              # :227 metric only
         ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, eC.input(self.sC_bd).data_ptr(), None, st),
                   "augment 3")
-        pl["C_bd_f"].run()                 # :228, :231
-        pl["C_bd_b"].run()
+        pl["C_bd_f"].run(prof)                 # :228, :231
+        pl["C_bd_b"].run(prof)
         ops.check(lib.combat_augment_bwd(self.sC_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[3], n, hw,
                                          self.d_bd.data_ptr(), 0, st), "augment 3 bwd")
         if eF is not None:                 # :245-247 metric only
             ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), st), "dct")
-            pl["F_f"].run()
+            pl["F_f"].run(prof)
             self.acc[4] += (self.sF.bufs["logits"].argmax(1) == 1).sum()
         ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[4], n, hw, eK.input(self.sK_bd).data_ptr(), None, st),
                   "augment 4")
-        pl["K_bd_f"].run()                 # :250-251
-        pl["K_bd_b"].run()
+        pl["K_bd_f"].run(prof)                 # :250-251
+        pl["K_bd_b"].run(prof)
         ops.check(lib.combat_augment_bwd(self.sK_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[4], n, hw,
                                          self.d_bd.data_ptr(), 1, st), "augment 4 bwd")
         l2_scale = float(opt.L2_weight) / float(n * 3 * hw * hw)          # :234, :253
         ops.check(lib.combat_trigger_bwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.d_bd.data_ptr(), bd_ptr,
                                          l2_scale, 1, self.sG.buf("g.z", (n, hw, hw, 8)).data_ptr(), st), "trigger bwd")
-        pl["G_b"].run()
+        pl["G_b"].run(prof)
         self._allreduce(eG)
         eG.fp.sgd_step(float(lr_g if lr_g is not None else opt.lr_G), grad_scale=1.0 / self.world)
         eG.mark_weights_dirty()
