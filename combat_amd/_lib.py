@@ -54,6 +54,7 @@ SIGNATURES = {
     "combat_conv_gemm": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
     "combat_conv_pick_tile": (C.c_int, [C.POINTER(ConvArgs)]),
     "combat_conv_stats_granule": (C.c_int, [C.c_int]),
+    "combat_conv_stats_layout": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(c_i32), C.POINTER(c_i32)]),
     "combat_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
     "combat_pack_weights": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32,
                                       c_i32, c_vp]),
@@ -89,6 +90,7 @@ SIGNATURES = {
 }
 
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x16, TILE_64x128 = 1, 2, 3, 4, 5
+TILE_H256x64, TILE_H128x128, TILE_H128x64, TILE_H64x64 = 6, 7, 8, 9
 
 
 class CombatHipError(RuntimeError):

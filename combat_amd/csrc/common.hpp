@@ -8,6 +8,10 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+// native 16-byte register type for staging arrays: copying HIP's uint4 *struct* from global memory
+// into a local array lowers to an address-space-crossing memcpy that SROA does not promote, which
+// leaves the array in scratch memory (and every prefetch waits for its own load)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 #define CB_LAUNCH_CHECK()                                  \
     do {                                                   \

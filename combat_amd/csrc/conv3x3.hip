@@ -1,0 +1,361 @@
+// 3x3 / stride-1 / pad-1 convolution (forward and input-gradient) with the input patch held in LDS.
+//
+// The generic gather kernel (conv_gemm.hip) re-fetches -- and re-normalises -- every input element
+// once per filter tap, which makes its main loop VALU-bound.  Here a workgroup owns a spatial patch
+// of BM output pixels (TI images x TH x TW) and BN output channels and, per 64-channel chunk of the
+// input, stages the (TH+2) x (TW+2) halo patch ONCE: global -> registers -> BatchNorm/InstanceNorm +
+// (Leaky)ReLU prologue -> LDS.  The nine taps are then nine MFMA passes whose pixel operand is the
+// same LDS image read at nine constant byte offsets; only the weight tile changes per tap (double
+// buffered through registers).  LDS rows are 160 bytes (128 + 32 pad): conflict-free ds_read_b128
+// for 16 consecutive pixels, and a tap is a plain address add (no swizzle to recompute).
+//
+// dgrad of such a convolution is the same kernel with the tap offset mirrored (2-r, 2-s) and the
+// transposed weight pack.  Everything after the accumulators is the shared fused epilogue.
+#include "conv_common.hpp"
+#include <cstdlib>
+
+namespace {
+
+constexpr int kRow = 160;  // bytes per LDS pixel / weight row (64 bf16 + pad)
+
+struct HaloParams {
+    combat_conv_args a;
+    int TW, TH, TI, HW, HH, HP;
+    int tw_shift, th_shift;
+    int tiles_x, tiles_y, tiles_m, tiles_n;
+    int PQ, nchunks;
+    int dbg;  // COMBAT_DEBUG_SKIP bits (timing ablations only): 1 staging, 2 taps, 4 epilogue
+};
+
+template <int BM>
+struct HaloMax {  // largest halo patch (pixels) a BM-pixel tile may need
+    static constexpr int HP = BM == 256 ? 400 : (BM == 128 ? 288 : 256);
+    static constexpr int ITERS = (HP * 8 + 255) / 256;
+};
+
+// weight tile of one (tap, channel chunk): global -> registers ... registers -> LDS.  Free functions
+// taking the register array by reference (capturing lambdas made the compiler keep it in scratch).
+template <int N>
+__device__ __forceinline__ void halo_load_w(u32x4_t (&rw)[N], const __bf16 *w_ptr, int kpad, int koff) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) rw[j] = *reinterpret_cast<const u32x4_t *>(w_ptr + (size_t)(32 * j) * kpad + koff);
+}
+
+template <int N>
+__device__ __forceinline__ void halo_store_w(const u32x4_t (&rw)[N], unsigned char *b, int w_row0, int w_chunk) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) *reinterpret_cast<u32x4_t *>(b + (w_row0 + 32 * j) * kRow + w_chunk * 16) = rw[j];
+}
+
+template <int BM, int BN, int WGM>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloParams p) {
+    using T = TileCfg<BM, BN, WGM>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const combat_conv_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wave_m = wid % T::WGM, wave_n = wid / T::WGM;
+
+    int tile_m, tile_n;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = swz % p.tiles_n;
+        tile_m = swz / p.tiles_n;
+    }
+    const int n0 = tile_n * BN;
+    const int tx_ = tile_m % p.tiles_x, ty_ = (tile_m / p.tiles_x) % p.tiles_y, ig = tile_m / (p.tiles_x * p.tiles_y);
+    const int img0 = ig * p.TI, oy0 = ty_ * p.TH, ox0 = tx_ * p.TW;
+    const int C = a.C, H = a.H, W = a.W;
+    const __bf16 *__restrict__ src = reinterpret_cast<const __bf16 *>(a.src);
+    const __bf16 *__restrict__ wp = reinterpret_cast<const __bf16 *>(a.wpack);
+    unsigned char *halo = smem;
+    unsigned char *wl = smem + ((p.HP * kRow + 15) & ~15);
+    const bool pro_affine = a.pro_scale != nullptr;
+
+    // per-lane LDS byte offsets of this wave's pixel fragments (tap (0,0) of the halo patch)
+    int hbase[T::FM];
+#pragma unroll
+    for (int j = 0; j < T::FM; ++j) {
+        const int pj = wave_m * T::WM + j * 16 + (lane & 15);
+        const int tx = pj & (p.TW - 1), ty = (pj >> p.tw_shift) & (p.TH - 1), ti = pj >> (p.tw_shift + p.th_shift);
+        hbase[j] = ((ti * p.HH + ty) * p.HW + tx) * kRow + (lane >> 4) * 16;
+    }
+    const int w_chunk = tid & 7, w_row0 = tid >> 3;
+    const __bf16 *w_ptr = wp + (size_t)(n0 + w_row0) * a.kpad + w_chunk * 8;
+    const int wfrag = (wave_n * T::WN + (lane & 15)) * kRow + (lane >> 4) * 16;
+
+    f32x4_t acc[T::FN][T::FM];
+#pragma unroll
+    for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // Weight tiles are prefetched TWO taps ahead through two register sets (rwa: even steps, rwb: odd
+    // steps of the linearised (chunk, tap) sequence), so a load has two MFMA phases to land before its
+    // registers are written to the LDS double buffer.
+    u32x4_t rwa[T::B_ITERS], rwb[T::B_ITERS];
+    const int nsteps = p.nchunks * 9;
+    auto koff_of = [&](int g) {  // reduction offset of linear step g = chunk * 9 + tap
+        const int cc = g / 9, tap = g - cc * 9;
+        return tap * C + cc * 64;
+    };
+    halo_load_w(rwa, w_ptr, a.kpad, koff_of(0));
+    if (nsteps > 1) halo_load_w(rwb, w_ptr, a.kpad, koff_of(1));
+
+    // ---- software-pipelined tap loop -----------------------------------------------------------
+    // A tap is two k-steps of (FM pixel + FN weight) fragments -> FM*FN MFMAs each.  Fragments live
+    // in two register sets: while the MFMAs of one k-step run, the ds_reads of the next are in
+    // flight.  sched_barrier pins "issue reads | MFMAs | (waits are inserted at first use)": left
+    // alone the compiler emits one ds_read + s_waitcnt lgkmcnt(0) per 4 MFMAs, an exposed LDS round
+    // trip every 64 MFMA cycles, which at 1-2 waves per SIMD made a tap cost ~3000 cycles.
+    bf16x8_t fp0[T::FM], fw0[T::FN], fp1[T::FM], fw1[T::FN];
+    auto tap_off = [&](int tap) {
+        const int r = (tap * 11) >> 5, s = tap - 3 * r;
+        return (a.mode == 0 ? (r * p.HW + s) : ((2 - r) * p.HW + (2 - s))) * kRow;
+    };
+    auto read_frags = [&](bf16x8_t (&fp)[T::FM], bf16x8_t (&fw)[T::FN], int tap, int ks, int buf) {
+        const int toff = tap_off(tap) + ks * 64;
+        const unsigned char *wb = wl + buf * (BN * kRow) + wfrag + ks * 64;
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j) fp[j] = *reinterpret_cast<const bf16x8_t *>(halo + hbase[j] + toff);
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i) fw[i] = *reinterpret_cast<const bf16x8_t *>(wb + i * 16 * kRow);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_frags = [&](const bf16x8_t (&fp)[T::FM], const bf16x8_t (&fw)[T::FN]) {
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fp[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one chunk = 9 taps; `b0` = LDS weight buffer of the chunk's first step (its parity); the
+    // register set holding step g+1 is rwb when g is even, rwa when g is odd
+    auto run_chunk = [&](auto parity_tag, int g0) {
+        constexpr int B0 = decltype(parity_tag)::value;
+        read_frags(fp0, fw0, 0, 0, B0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int g = g0 + tap;
+            const int buf = (B0 + tap) & 1;
+            // phase A: k-step 0 of this tap; fetch k-step 1
+            read_frags(fp1, fw1, tap, 1, buf);
+            mfma_frags(fp0, fw0);
+            // weights of the next step go to the other buffer (free since the previous tap's barrier)
+            if (g + 1 < nsteps) {
+                if (buf == 0) halo_store_w(rwb, wl + BN * kRow, w_row0, w_chunk);
+                else halo_store_w(rwa, wl, w_row0, w_chunk);
+            }
+            if (g + 2 < nsteps) {
+                if (buf == 0) halo_load_w(rwa, w_ptr, a.kpad, koff_of(g + 2));
+                else halo_load_w(rwb, w_ptr, a.kpad, koff_of(g + 2));
+            }
+            __syncthreads();
+            // phase B: k-step 1; fetch k-step 0 of the next tap (same chunk only: the halo changes)
+            if (tap < 8) read_frags(fp0, fw0, tap + 1, 0, buf ^ 1);
+            mfma_frags(fp1, fw1);
+        }
+    };
+
+    int g = 0;  // linear step; LDS weight buffer of step g is g & 1, its registers rwa (even) / rwb (odd)
+    for (int cc = 0; cc < p.nchunks; ++cc) {
+        if (!(p.dbg & 1))
+        // ---- stage the halo patch of this channel chunk (prologue applied once per element)
+        {
+            uint4 rh[HaloMax<BM>::ITERS];
+            int gofs[HaloMax<BM>::ITERS];
+            const int total = p.HP * 8;
+#pragma unroll
+            for (int it = 0; it < HaloMax<BM>::ITERS; ++it) {
+                const int idx = tid + 256 * it;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                gofs[it] = -1;
+                if (idx < total) {
+                    const int hp = idx >> 3, ch = idx & 7;
+                    const int hx = hp % p.HW, t = hp / p.HW;
+                    const int hy = t % p.HH, ti = t / p.HH;
+                    const int img = img0 + ti, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+                    if (img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                        v = *reinterpret_cast<const uint4 *>(src + ((size_t)(img * H + iy) * W + ix) * C + cc * 64 + ch * 8);
+                        gofs[it] = img * a.pro_group_stride + cc * 64 + ch * 8;
+                    }
+                }
+                rh[it] = v;
+            }
+            // the (scale, shift) pair depends on the channel chunk (tid & 7, the same in every
+            // iteration) and, for InstanceNorm, on the image: loop invariant unless a tile spans images
+            auto stage = [&](auto uniform_tag) {
+            constexpr bool tab_uniform = decltype(uniform_tag)::value;
+            float sc[8], sh[8];
+            if (pro_affine && tab_uniform) {
+                const int g0 = (img0 < a.N ? img0 : 0) * a.pro_group_stride + cc * 64 + (tid & 7) * 8;
+                load8f(a.pro_scale + g0, sc);
+                load8f(a.pro_shift + g0, sh);
+            }
+#pragma unroll
+            for (int it = 0; it < HaloMax<BM>::ITERS; ++it) {
+                const int idx = tid + 256 * it;
+                if (idx < total) {
+                    uint4 val = rh[it];
+                    if ((pro_affine || a.pro_act) && gofs[it] >= 0) {
+                        float v[8];
+                        unpack8(val, v);
+                        if (pro_affine) {
+                            if constexpr (!tab_uniform) {
+                                load8f(a.pro_scale + gofs[it], sc);
+                                load8f(a.pro_shift + gofs[it], sh);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+                        }
+                        if (a.pro_act) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.pro_slope;
+                        }
+                        val = pack8(v);
+                    }
+                    *reinterpret_cast<uint4 *>(halo + (idx >> 3) * kRow + (idx & 7) * 16) = val;
+                }
+            }
+            };
+            if (a.pro_group_stride == 0 || p.TI == 1) stage(std::true_type{}); else stage(std::false_type{});
+        }
+        if (cc == 0) halo_store_w(rwa, wl, w_row0, w_chunk);   // step 0 -> buffer 0 (later chunks: done in the tap loop)
+        __syncthreads();
+        if (p.dbg & 2) { g += 9; continue; }
+        // ---- nine taps (parity of the first step alternates between chunks: two instantiations)
+        if ((g & 1) == 0) run_chunk(std::integral_constant<int, 0>{}, g);
+        else run_chunk(std::integral_constant<int, 1>{}, g);
+        g += 9;
+        __syncthreads();   // every wave is done with this chunk's halo image before it is restaged
+    }
+
+    if (p.dbg & 4) {
+        if (acc[0][0][0] == 123.456f) reinterpret_cast<float *>(a.dst)[tid] = acc[0][0][1];
+        return;
+    }
+    conv_epilogue<T>(smem, acc, a, n0, p.PQ,
+                     [&](int row) {
+                         const int tx = row & (p.TW - 1), ty = (row >> p.tw_shift) & (p.TH - 1);
+                         const int img = img0 + (row >> (p.tw_shift + p.th_shift));
+                         return img < a.N ? (img * H + oy0 + ty) * W + ox0 + tx : -1;
+                     },
+                     tile_m * 4 + wid);
+}
+
+bool geometry(const combat_conv_args *a, int BM, int BN, HaloParams &p, int &smem) {
+    const int W = a->W, H = a->H;
+    int TW = W < 16 ? W : 16;
+    int TH = H < BM / TW ? H : BM / TW;
+    int TI = BM / (TW * TH);
+    if (TI < 1 || TW * TH * TI != BM) return false;
+    p.a = *a;
+    p.TW = TW; p.TH = TH; p.TI = TI;
+    p.HW = TW + 2; p.HH = TH + 2; p.HP = TI * p.HH * p.HW;
+    p.tw_shift = ilog2_exact(TW); p.th_shift = ilog2_exact(TH);
+    if (p.tw_shift < 0 || p.th_shift < 0 || W % TW || H % TH) return false;
+    const int hpmax = BM == 256 ? 400 : (BM == 128 ? 288 : 256);
+    if (p.HP > hpmax) return false;
+    p.tiles_x = W / TW; p.tiles_y = H / TH;
+    p.tiles_m = p.tiles_x * p.tiles_y * ((a->N + TI - 1) / TI);
+    p.tiles_n = (a->K + BN - 1) / BN;
+    if (p.tiles_n * BN > a->rows_pad) return false;
+    p.PQ = H * W;
+    p.nchunks = a->C / 64;
+    {
+        static const char *e = getenv("COMBAT_DEBUG_SKIP");
+        p.dbg = e ? atoi(e) : 0;
+    }
+    const int stage = ((p.HP * kRow + 15) & ~15) + 2 * BN * kRow;
+    const int ep = BM * (BN + 4) * 4;
+    smem = stage > ep ? stage : ep;
+    return smem <= 150 * 1024;
+}
+
+template <int BM, int BN, int WGM>
+int launch_halo(const HaloParams &p, int smem, hipStream_t st) {
+    auto kern = conv3x3_halo_kernel<BM, BN, WGM>;
+    static int attr_bytes = 0;
+    if (smem > attr_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_bytes = 150 * 1024;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+struct Cand {
+    int tile, BM, BN;
+};
+const Cand kCands[] = {{COMBAT_TILE_H256x64, 256, 64}, {COMBAT_TILE_H128x128, 128, 128},
+                       {COMBAT_TILE_H128x64, 128, 64}, {COMBAT_TILE_H64x64, 64, 64}};
+
+bool applicable(const combat_conv_args *a) {
+    return a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->P == a->H && a->Q == a->W &&
+           a->C >= 64 && (a->C & 63) == 0 && a->K >= 64 && (a->K & 63) == 0 && a->kpad >= 9 * a->C;
+}
+
+}  // namespace
+
+// tile id (COMBAT_TILE_H*) the halo kernel would use for these args, or 0 if it does not apply
+int conv3x3_pick(const combat_conv_args *a) {
+    if (!applicable(a)) return 0;
+    if (a->tile) {
+        for (const Cand &c : kCands)
+            if (c.tile == a->tile) {
+                HaloParams p;
+                int smem;
+                return geometry(a, c.BM, c.BN, p, smem) ? c.tile : 0;
+            }
+        return 0;
+    }
+    // Measured on MI355X (profiles/r01_b_tile_sweep.txt): the 128x64 tile wins while it yields >= 512
+    // workgroups (2 per CU), the 64x64 tile below that; the 4-wave-wide tiles (256x64, 128x128) need
+    // > 300 VGPRs once the tap loop is software-pipelined and are kept for explicit requests only.
+    HaloParams p;
+    int smem;
+    const bool ok8 = geometry(a, 128, 64, p, smem);
+    const long blocks8 = ok8 ? (long)p.tiles_m * p.tiles_n : 0;
+    if (ok8 && blocks8 >= 512) return COMBAT_TILE_H128x64;
+    if (geometry(a, 64, 64, p, smem)) return COMBAT_TILE_H64x64;
+    return ok8 ? COMBAT_TILE_H128x64 : 0;
+}
+
+int conv3x3_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {
+    for (const Cand &c : kCands)
+        if (c.tile == tile) {
+            HaloParams p;
+            int smem;
+            if (!geometry(a, c.BM, c.BN, p, smem)) return COMBAT_EINVAL;
+            *rows = p.tiles_m * 4;
+            const int part = c.BM / 4;  // rows of one wave
+            *rows_per_image = ((p.TW * p.TH) % part == 0) ? (a->H * a->W) / part : 0;
+            return COMBAT_OK;
+        }
+    return COMBAT_EINVAL;
+}
+
+int conv3x3_launch(const combat_conv_args *a, int tile, hipStream_t st) {
+    HaloParams p;
+    int smem;
+    switch (tile) {
+        case COMBAT_TILE_H256x64:
+            if (!geometry(a, 256, 64, p, smem)) return COMBAT_EINVAL;
+            return launch_halo<256, 64, 4>(p, smem, st);
+        case COMBAT_TILE_H128x128:
+            if (!geometry(a, 128, 128, p, smem)) return COMBAT_EINVAL;
+            return launch_halo<128, 128, 2>(p, smem, st);
+        case COMBAT_TILE_H128x64:
+            if (!geometry(a, 128, 64, p, smem)) return COMBAT_EINVAL;
+            return launch_halo<128, 64, 2>(p, smem, st);
+        case COMBAT_TILE_H64x64:
+            if (!geometry(a, 64, 64, p, smem)) return COMBAT_EINVAL;
+            return launch_halo<64, 64, 2>(p, smem, st);
+        default: return COMBAT_EINVAL;
+    }
+}

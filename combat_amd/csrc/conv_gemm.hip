@@ -20,7 +20,7 @@
 // classifier_models/preact_resnet.py:21,23,27-29,77, classifier_models/resnet.py:20,22,27-30,72,
 // networks/models.py:275-314, defenses/frequency_based/model.py:13-39, together with the
 // normalisation/activation/residual element-wise ops around them.
-#include "common.hpp"
+#include "conv_common.hpp"
 
 namespace {
 
@@ -33,25 +33,6 @@ struct ConvParams {
     int s_shift;  // log2(stride)
     int nkt;      // reduction steps of 64
     int tiles_m, tiles_n;
-};
-
-template <int BM, int BN>
-struct TileCfg {
-    static constexpr int WGM = (BN == 16) ? 4 : 2;
-    static constexpr int WGN = 4 / WGM;
-    static constexpr int WM = BM / WGM;
-    static constexpr int WN = BN / WGN;
-    static constexpr int FM = WM / 16;
-    static constexpr int FN = WN / 16;
-    static constexpr int A_ITERS = BM / 32;
-    static constexpr int B_ITERS = (BN + 31) / 32;
-    static constexpr int EPS = BN + 4;  // fp32 epilogue row stride
-    static constexpr int STAGE_BYTES = 2 * (BM + BN) * 128;
-    static constexpr int EP_BYTES = BM * EPS * 4;
-    static constexpr int SMEM = STAGE_BYTES > EP_BYTES ? STAGE_BYTES : EP_BYTES;
-    static constexpr int NC = BN / 8;             // 16-byte chunks per dst row
-    static constexpr int RPT = BM * NC / 256;     // dst rows per thread in the epilogue
-    static constexpr int SG = BM / 4;             // rows covered by one wave = statistics granule
 };
 
 __device__ __forceinline__ int lds_off(int row, int kchunk) { return row * 128 + ((kchunk ^ ((row >> 1) & 7)) << 4); }
@@ -105,7 +86,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const bool b_active = (BN >= 32) || (tid < BN * 8);
     const __bf16 *b_ptr = wp + (size_t)(n0 + a_row0) * a.kpad + a_chunk * 8;
 
-    uint4 ra[T::A_ITERS], rb[T::B_ITERS];
+    uint4 ra[T::A_ITERS];
+    u32x4_t rb[T::B_ITERS];
     unsigned ra_valid = 0;
     float pscale[8], pshift[8];  // BatchNorm-style prologue (group stride 0): prefetched with the tile
     const bool pro_affine = a.pro_scale != nullptr;
@@ -143,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (b_active) {
 #pragma unroll
             for (int j = 0; j < T::B_ITERS; ++j)
-                rb[j] = *reinterpret_cast<const uint4 *>(b_ptr + (size_t)(32 * j) * a.kpad + kt * 64);
+                rb[j] = *reinterpret_cast<const u32x4_t *>(b_ptr + (size_t)(32 * j) * a.kpad + kt * 64);
         }
         if (pro_shared && tap_ok) {
             load8f(a.pro_scale + ci, pscale);
@@ -182,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < T::B_ITERS; ++j) {
                 const int row = a_row0 + 32 * j;
-                *reinterpret_cast<uint4 *>(bl + lds_off(row, a_chunk)) = rb[j];
+                *reinterpret_cast<u32x4_t *>(bl + lds_off(row, a_chunk)) = rb[j];
             }
         }
     };
@@ -226,123 +208,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: accumulators -> fp32 LDS image -> row-major fused tail
-    float *ep = reinterpret_cast<float *>(smem);
+    // ---- epilogue (shared with the halo kernel)
     {
-        const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-        for (int i = 0; i < T::FN; ++i)
-#pragma unroll
-            for (int j = 0; j < T::FM; ++j) {
-                const int n = wave_n * T::WN + i * 16 + fq * 4;
-                const int row = wave_m * T::WM + j * 16 + fr;
-                *reinterpret_cast<f32x4_t *>(ep + row * T::EPS + n) = acc[i][j];
-            }
-    }
-    __syncthreads();
-
-    const int K = a.K;
-    const int cc = tid % T::NC, rgrp = tid / T::NC;
-    const int n = n0 + cc * 8;
-    const bool n_ok = n < K;
-    float bias8[8];
-    if (a.bias && n_ok) load8f(a.bias + n, bias8);
-    float s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    __bf16 *__restrict__ dst = reinterpret_cast<__bf16 *>(a.dst);
-
-#pragma unroll
-    for (int pr = 0; pr < T::RPT; ++pr) {
-        const int row = rgrp * T::RPT + pr;
-        const int m = m0 + row;
-        if (m >= p.M || !n_ok) continue;
-        float v[8];
-        load8f(ep + row * T::EPS + cc * 8, v);
-        const size_t off = (size_t)m * K + n;
-        if (a.bias) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-        }
-        if (a.add_pre) {
-            float t[8];
-            unpack8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const __bf16 *>(a.add_pre) + off), t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-        float xm[8];
-        int g = 0;
-        if (a.mask_x) {
-            unpack8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const __bf16 *>(a.mask_x) + off), xm);
-            g = (m / p.PQ) * a.mask_group_stride;
-            if (a.mask_scale) {
-                float sc[8], sh[8];
-                load8f(a.mask_scale + g + n, sc);
-                load8f(a.mask_shift + g + n, sh);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float q = fmaf(xm[e], sc[e], sh[e]);
-                    float d = q > 0.f ? 1.f : a.mask_slope;
-                    if (a.mask_mul_scale) d *= sc[e];
-                    v[e] *= d;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= xm[e] > 0.f ? 1.f : a.mask_slope;
-            }
-        }
-        if (a.add_post) {
-            float t[8];
-            unpack8(*reinterpret_cast<const uint4 *>(reinterpret_cast<const __bf16 *>(a.add_post) + off), t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e];
-        }
-        if (a.tanh_out) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
-        }
-        const uint4 packed = pack8(v);
-        *reinterpret_cast<uint4 *>(dst + off) = packed;
-        if (a.stats_kind) {
-            float vr[8];
-            unpack8(packed, vr);
-            if (a.stats_kind == 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1[e] += vr[e];
-                    s2[e] = fmaf(vr[e], vr[e], s2[e]);
-                }
-            } else {
-                float hr[8], hm[8];
-                load8f(a.xh_rstd + g + n, hr);
-                load8f(a.xh_mean + g + n, hm);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1[e] += vr[e];
-                    s2[e] = fmaf(vr[e], (xm[e] - hm[e]) * hr[e], s2[e]);
-                }
-            }
-        }
-    }
-    if (a.stats_kind) {
-        // lanes of one wave with equal cc differ by multiples of NC
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-#pragma unroll
-            for (int o = T::NC; o < 64; o <<= 1) {
-                s1[e] += __shfl_xor(s1[e], o);
-                s2[e] += __shfl_xor(s2[e], o);
-            }
-        }
         const int gi = m0 / T::SG + wid;
-        if (lane < T::NC && n_ok && gi * T::SG < p.M) {
-            float *o1 = a.stats + ((size_t)gi * 2) * K + n;
-            float *o2 = o1 + K;
-            *reinterpret_cast<float4 *>(o1) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-            *reinterpret_cast<float4 *>(o1 + 4) = make_float4(s1[4], s1[5], s1[6], s1[7]);
-            *reinterpret_cast<float4 *>(o2) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-            *reinterpret_cast<float4 *>(o2 + 4) = make_float4(s2[4], s2[5], s2[6], s2[7]);
-        }
+        conv_epilogue<T>(smem, acc, a, n0, p.PQ, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; },
+                         gi * T::SG < p.M ? gi : -1);
     }
 }
 
@@ -367,6 +237,8 @@ int launch(const ConvParams &p, hipStream_t st) {
 }
 
 int pick_tile(const combat_conv_args *a) {
+    if (const int halo = conv3x3_pick(a)) return halo;   // 3x3 / stride 1 with the patch held in LDS
+    if (a->tile >= COMBAT_TILE_H256x64) return 0;        // a halo tile was forced but does not apply
     if (a->tile) return a->tile;
     const long M = (long)a->N * a->P * a->Q;
     if (a->K <= 16) return COMBAT_TILE_128x16;
@@ -382,13 +254,29 @@ extern "C" int combat_conv_pick_tile(const combat_conv_args *a) { return a ? pic
 
 extern "C" int combat_conv_stats_granule(int tile) {
     switch (tile) {
+        case COMBAT_TILE_H256x64: return 64;
         case COMBAT_TILE_128x128:
         case COMBAT_TILE_128x64:
-        case COMBAT_TILE_128x16: return 32;
+        case COMBAT_TILE_128x16:
+        case COMBAT_TILE_H128x128:
+        case COMBAT_TILE_H128x64: return 32;
         case COMBAT_TILE_64x64:
-        case COMBAT_TILE_64x128: return 16;
+        case COMBAT_TILE_64x128:
+        case COMBAT_TILE_H64x64: return 16;
         default: return COMBAT_EINVAL;
     }
+}
+
+extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows, int32_t *rows_per_image) {
+    if (!a || !rows || !rows_per_image) return COMBAT_EINVAL;
+    const int tile = pick_tile(a);
+    if (tile >= COMBAT_TILE_H256x64) return conv3x3_stats_layout(a, tile, rows, rows_per_image);
+    const int gran = combat_conv_stats_granule(tile);
+    if (gran <= 0) return COMBAT_EINVAL;
+    const long M = (long)a->N * a->P * a->Q, PQ = (long)a->P * a->Q;
+    *rows = (int)((M + gran - 1) / gran);
+    *rows_per_image = (PQ % gran == 0) ? (int)(PQ / gran) : 0;
+    return COMBAT_OK;
 }
 
 extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
@@ -420,7 +308,9 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     if (need < p.nkt) p.nkt = need;
     p.tiles_m = p.tiles_n = 0;
     hipStream_t st = as_stream(stream);
-    switch (pick_tile(a)) {
+    const int tile = pick_tile(a);
+    if (tile >= COMBAT_TILE_H256x64) return conv3x3_launch(a, tile, st);
+    switch (tile) {
         case COMBAT_TILE_128x128: return launch<128, 128>(p, st);
         case COMBAT_TILE_128x64: return launch<128, 64>(p, st);
         case COMBAT_TILE_64x64: return launch<64, 64>(p, st);

