@@ -1,0 +1,109 @@
+"""Input side of the step (reference: utils/dataloader.py:24-42, 98-123; utils/dataloader_cleanbd.py
+:131-193) without torchvision: CIFAR-10 is read from the standard python or binary batches, images
+get the reference's ToTensor + Normalize(0.5, 0.5) ((u8/255 - 0.5)/0.5), batches come out as pinned
+float32 [B,3,32,32] + int64 labels on the HOST, as a torch DataLoader would yield them.  The whole
+set (150 MB of uint8) stays in RAM, so there are no worker processes; shuffling draws one
+``torch.randperm`` per epoch from torch's global generator like DataLoader's RandomSampler.  Nothing is
+downloaded: a missing dataset is an error unless ``--synthetic`` asks for CIFAR-10-shaped noise."""
+from __future__ import annotations
+
+import os
+import pickle
+import random
+from typing import Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+
+CIFAR_TRAIN, CIFAR_TEST = 50000, 10000
+
+
+def _load_cifar10(root: str, train: bool) -> Tuple[np.ndarray, np.ndarray]:
+    py = os.path.join(root, "cifar-10-batches-py")
+    bn = os.path.join(root, "cifar-10-batches-bin")
+    if os.path.isdir(py):
+        names = ["data_batch_%d" % i for i in range(1, 6)] if train else ["test_batch"]
+        xs, ys = [], []
+        for n in names:
+            with open(os.path.join(py, n), "rb") as f:
+                d = pickle.load(f, encoding="latin1")   # the public dataset's own format (user data)
+            xs.append(np.asarray(d["data"], np.uint8).reshape(-1, 3, 32, 32))
+            ys.append(np.asarray(d.get("labels", d.get("fine_labels")), np.int64))
+        return np.concatenate(xs), np.concatenate(ys)
+    if os.path.isdir(bn):
+        names = ["data_batch_%d.bin" % i for i in range(1, 6)] if train else ["test_batch.bin"]
+        raw = np.concatenate([np.fromfile(os.path.join(bn, n), np.uint8).reshape(-1, 3073) for n in names])
+        return raw[:, 1:].reshape(-1, 3, 32, 32).copy(), raw[:, 0].astype(np.int64)
+    raise FileNotFoundError(
+        "CIFAR-10 not found under %r (expected cifar-10-batches-py/ or cifar-10-batches-bin/); nothing is "
+        "downloaded here -- pass --synthetic for CIFAR-10-shaped random data" % root)
+
+
+def synthetic_cifar10(n: int, seed: int, hw: int = 32, classes: int = 10) -> Tuple[np.ndarray, np.ndarray]:
+    g = np.random.default_rng(seed)
+    return g.integers(0, 256, (n, 3, hw, hw), dtype=np.uint8), g.integers(0, classes, n).astype(np.int64)
+
+
+class ArrayLoader:
+    """Minimal DataLoader stand-in over in-memory uint8 images: ``len()`` = batches per epoch, iteration
+    yields (inputs, targets[, poisoned]).  ``rank``/``world`` give each data-parallel rank a disjoint
+    strided shard of every epoch's permutation (same permutation on all ranks: seed it identically)."""
+
+    def __init__(self, images: np.ndarray, labels: np.ndarray, bs: int, shuffle: bool, poisoned: Optional[np.ndarray] = None,
+                 rank: int = 0, world: int = 1, drop_last: bool = False):
+        self.x = torch.from_numpy(np.ascontiguousarray(images))
+        self.y = torch.from_numpy(np.ascontiguousarray(labels))
+        self.poisoned = None if poisoned is None else torch.from_numpy(poisoned.astype(np.bool_))
+        self.bs, self.shuffle, self.rank, self.world, self.drop_last = bs, shuffle, rank, world, drop_last
+        self.dataset = self  # len(loader.dataset)
+
+    def _count(self) -> int:
+        n = self.x.shape[0]
+        return (n - self.rank + self.world - 1) // self.world
+
+    def __len__(self) -> int:
+        n = self._count()
+        return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
+
+    def __iter__(self) -> Iterator:
+        n = self.x.shape[0]
+        order = torch.randperm(n) if self.shuffle else torch.arange(n)
+        order = order[self.rank::self.world]
+        for i in range(len(self)):
+            idx = order[i * self.bs:(i + 1) * self.bs]
+            xb = ((self.x[idx].float() / 255.0) - 0.5) / 0.5
+            xb = xb.pin_memory() if torch.cuda.is_available() else xb
+            if self.poisoned is None:
+                yield xb, self.y[idx]
+            else:
+                yield xb, self.y[idx], self.poisoned[idx]
+
+
+def poison_flags(labels: np.ndarray, opt, n_classes: int) -> np.ndarray:
+    """utils/dataloader_cleanbd.py:142-150: a fixed random subset (``random.sample``, Python's global
+    RNG) of int(pc * #target-class images) images is marked poisoned, once per dataset."""
+    target = {opt.target_label} if opt.attack_mode == "all2one" else set(range(n_classes))
+    ids = [i for i, l in enumerate(labels.tolist()) if int(l) in target]
+    num = max(0, int(opt.pc * len(ids)))
+    print(f"Poison {num} images ({opt.pc * len(ids)})")
+    flags = np.zeros(len(labels), np.bool_)
+    flags[random.sample(ids, num)] = True
+    return flags
+
+
+def get_dataloader(opt, train: bool = True, pretensor_transform: bool = False, bs: Optional[int] = None,
+                   shuffle: bool = True, poisoned: bool = False, rank: int = 0, world: int = 1) -> ArrayLoader:
+    """Same call shape as the reference's ``get_dataloader`` (utils/dataloader.py:98,
+    utils/dataloader_cleanbd.py:161 with ``poisoned=True``)."""
+    bs = opt.bs if bs is None else bs
+    if opt.dataset != "cifar10":
+        raise Exception("dataset %r: only cifar10 is wired to the HIP path this round (SURVEY section 8(f))" % opt.dataset)
+    if getattr(opt, "synthetic", False):
+        n = getattr(opt, "synthetic_size", 0) or (CIFAR_TRAIN if train else CIFAR_TEST)
+        x, y = synthetic_cifar10(n, 1234 if train else 4321, opt.input_height, opt.num_classes)
+    else:
+        x, y = _load_cifar10(opt.data_root, train)
+    if getattr(opt, "debug", False):                         # utils/dataloader.py:118-119
+        x, y = x[:1000], y[:1000]
+    flags = poison_flags(y, opt, opt.num_classes) if poisoned else None
+    return ArrayLoader(x, y, bs, shuffle, flags, rank, world)

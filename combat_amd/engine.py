@@ -36,6 +36,7 @@ class Plan:
         self.name = name
         self.calls: List[Tuple] = []
         self._keep: List = []
+        self.marks: Dict[int, int] = {}   # call index -> flat-gradient offset complete after that call
 
     def add(self, what: str, cfunc, *args) -> None:
         self.calls.append((cfunc, args, what))
@@ -43,12 +44,18 @@ class Plan:
     def hold(self, *objs) -> None:
         self._keep.extend(objs)
 
-    def run(self, prof: Optional[list] = None) -> None:
+    def mark(self, grad_offset: int) -> None:
+        """Every gradient at flat offset >= grad_offset is final once the calls recorded so far ran."""
+        self.marks[len(self.calls) - 1] = grad_offset
+
+    def run(self, prof: Optional[list] = None, on_mark=None) -> None:
         """Replay.  `prof` (a list) switches on per-launch HIP-event bracketing of the convolution
-        kernels on the launch stream: it receives (plan/what, ConvArgs, start_event, end_event)."""
+        kernels on the launch stream: it receives (plan/what, ConvArgs, start_event, end_event).
+        `on_mark(offset)` is called right after the call that completes the gradients above `offset`
+        has been enqueued (data-parallel bucketed all-reduce overlapping the rest of the backward)."""
         stream = torch.cuda.current_stream()
         st = stream.cuda_stream
-        for cfunc, args, what in self.calls:
+        for ci, (cfunc, args, what) in enumerate(self.calls):
             if prof is not None and cfunc is lib.combat_conv_gemm:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
@@ -60,6 +67,8 @@ class Plan:
             if rc:
                 kind = {-1: "invalid shape/argument", -2: "HIP launch failed"}.get(rc, "status %d" % rc)
                 raise CombatHipError("%s/%s: %s" % (self.name, what, kind))
+            if on_mark is not None and ci in self.marks:
+                on_mark(self.marks[ci])
 
     def __len__(self):
         return len(self.calls)
@@ -497,7 +506,10 @@ class PreActEngine(NetEngine):
             dxin = slot.buf("g.b%d.dx" % b, xin.shape)
             self._bwd_apply(P, "g." + blk.bn1.prefix, dz1, xin, dxin, st1, add=None if blk.sc is not None else d_out)
             d_out = dxin
+            if b in (6, 4, 2):   # layer4 / layer3 / layer2 complete: their gradient range can travel
+                P.mark(fp.offsets[pre + "bn1.weight"][0])
         rec_wgrad(P, "stem.wgrad", self.input(slot), d_out, self.stem, fp.grad_phys("conv1.weight"))
+        P.mark(0)
         slot.plans[key] = P
         return P
 
@@ -682,6 +694,7 @@ class UnetEngine(NetEngine):
         du2, d = through_up("upconv2_1", d, pc["upconv2_1"], 2, "upconv3_0")
         d = through_norm("upconv3_0", d, pc["upconv3_0"], "upconv3_1")
         _, d = through_up("upconv3_1", d, pc["upconv3_1"], 3, "conv3_1")
+        P.mark(fp.offsets["upconv3_1.weight"][0])          # decoder gradients complete
         d = through_norm("conv3_1", d, pc["conv3_1"], "conv3_0")
         d = through_norm("conv3_0", d, pc["conv3_0"], "conv2_1", add_pre=du2)
         d = through_norm("conv2_1", d, pc["conv2_1"], "conv2_0")
@@ -697,6 +710,7 @@ class UnetEngine(NetEngine):
         P.add("db.conv0_0", lib.combat_colsum, d00.data_ptr(), d00.numel() // d00.shape[-1], d00.shape[-1],
               d00.shape[-1], fp.grad_phys("conv0_0.bias").data_ptr())
         rec_wgrad(P, "conv0_0.wgrad", self.input(slot), d00, pc["conv0_0"], fp.grad_phys("conv0_0.weight"))
+        P.mark(0)
         slot.plans["bwd"] = P
         return P
 
@@ -772,6 +786,13 @@ def _images_to_c8(x: torch.Tensor, dst: torch.Tensor) -> None:
     ops.image_to_c8(x.contiguous().float(), dst)
 
 
+def pad_batch(n: int) -> int:
+    """Inference batches are rounded up to a multiple of 16 so that ragged sizes (the non-target subset
+    of a test batch) share slots and plans; every sample is independent in eval mode (BatchNorm uses
+    running statistics, InstanceNorm is per sample), so the padding rows change nothing."""
+    return max(16, (n + 15) // 16 * 16)
+
+
 class _ClassifierFn(torch.autograd.Function):
     """logits = netC(x) through the HIP plans.  Backward supports the two uses the reference
     makes of a classifier: train mode -> parameter gradients; eval mode -> input gradient."""
@@ -782,13 +803,13 @@ class _ClassifierFn(torch.autograd.Function):
         eng.refresh()
         n, _, hw, _ = x.shape
         train = module.training
-        slot = eng.slot("module.train" if train else "module.eval", n, hw)
+        slot = eng.slot("module.train" if train else "module.eval", n if train else pad_batch(n), hw)
         _images_to_c8(x, eng.input(slot))
         eng.forward_plan(slot, train).run()
         if train:
             eng.fold_bn()
         ctx.module, ctx.slot, ctx.train = module, slot, train
-        return eng.head_bufs(slot)["logits"].clone()
+        return eng.head_bufs(slot)["logits"][:n].clone()
 
     @staticmethod
     def backward(ctx, dlogits):
@@ -804,12 +825,12 @@ class _GeneratorFn(torch.autograd.Function):
         n, _, hw, _ = x.shape
         if n == 0:
             return x.new_zeros(x.shape)
-        slot = eng.slot("module", n, hw)
+        slot = eng.slot("module", pad_batch(n), hw)
         _images_to_c8(x, eng.input(slot))
         eng.forward_plan(slot).run()
-        out = torch.empty(n, 3, hw, hw, dtype=f32, device=x.device)
+        out = torch.empty(slot.N, 3, hw, hw, dtype=f32, device=x.device)
         ops.nhwc_to_nchw_f32(eng.output(slot), 3, out)
-        return out
+        return out[:n]
 
     @staticmethod
     def backward(ctx, g):
@@ -830,8 +851,8 @@ def module_forward(module, x: torch.Tensor) -> torch.Tensor:
         eng = module._net_engine()
         eng.refresh()
         n, _, hw, _ = x.shape
-        slot = eng.slot("module", n, hw)
+        slot = eng.slot("module", pad_batch(n), hw)
         ops.image_to_c8(x.contiguous().float(), eng.input(slot))  # hi/lo split keeps the DCT's dynamic range
         eng.forward_plan(slot).run()
-        return slot.bufs["logits"].clone()
+        return slot.bufs["logits"][:n].clone()
     raise NotImplementedError(module.arch)

@@ -25,6 +25,7 @@ import torch
 from . import ops, trigger
 from ._lib import lib
 from .augment import PostTensorTransform
+from .dist import GradReducer, bucket_ranges
 from .engine import FreqEngine, PreActEngine, UnetEngine, f32
 
 BUCKETS = (8, 16, 32, 64, 128, 256, 512, 1024)
@@ -73,6 +74,28 @@ def draw_randomness(targets_cpu: torch.Tensor, bd_targets_cpu: torch.Tensor, opt
     return StepRandomness(num_bd, sigma_c, sigma_g, [aug0, aug1, aug2, aug3, aug4])
 
 
+def poison_tables(targets: torch.Tensor, bd_targets: torch.Tensor, num_bd: int):
+    """Host-side index tables of Phase C (train_generator.py:181-204).  The batch is re-ordered
+    [first num_bd target-class images (poisoned), remaining target-class images, all others]:
+      perm         int32 [n]  source image of every row of the re-ordered batch
+      total_targets int64 [n] labels of the re-ordered batch (poisoned rows carry bd_targets)
+      idx_small    int32 [n]  first num_bd entries = images handed to the generator
+      idx_total    int32 [n]  gather indices into the [inputs ; triggered images] staging buffer
+                               (rows < num_bd read the triggered copies at n + i)"""
+    n = targets.shape[0]
+    trg = (targets == bd_targets).nonzero()[:, 0]
+    ntrg = (targets != bd_targets).nonzero()[:, 0]
+    perm = torch.cat([trg, ntrg]).to(torch.int32)
+    total_targets = targets[perm.long()].clone()
+    total_targets[:num_bd] = bd_targets[perm[:num_bd].long()]
+    idx_small = torch.zeros(n, dtype=torch.int32)
+    idx_small[:num_bd] = perm[:num_bd]
+    idx_total = perm.clone()
+    if num_bd:
+        idx_total[:num_bd] = torch.arange(n, n + num_bd, dtype=torch.int32)
+    return perm, total_targets, idx_small, idx_total
+
+
 class AlternatedStep:
     """Owns the engines, slots and small device tables of one rank's step."""
 
@@ -96,10 +119,25 @@ class AlternatedStep:
         self.acc = torch.zeros(8, dtype=torch.float64, device=dev)  # running sums for logging
         self._host = None
         self.steps_done = 0
+        self._reducers = {}
+        self._sets: Dict[int, dict] = {}
 
     # ------------------------------------------------------------------ buffers per batch size
+    _PER_N = ("inputs", "cat_src", "bd", "d_bd", "mse", "tab_f", "tab_i", "h_tab_f", "h_tab_i", "h_k1", "h_targets",
+              "d_targets", "sC_train", "sC_clean", "sC_bd", "sK_clean", "sK_bd", "sG", "sF", "pl", "_targets_of",
+              "_gen_small")
+
     def _setup(self, n: int):
+        """Buffers, slots and plans are per batch size and cached: the ragged last batch of an epoch
+        (80 images for CIFAR-10) gets its own set once and the metric counters of every set survive."""
         if n == self.N:
+            return
+        if self.N:
+            self._sets[self.N] = {k: getattr(self, k) for k in self._PER_N}
+        if n in self._sets:
+            for k, v in self._sets[n].items():
+                setattr(self, k, v)
+            self.N = n
             return
         self.N, dev, hw = n, self.dev, self.hw
         self.inputs = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)
@@ -163,20 +201,12 @@ class AlternatedStep:
             rnd = draw_randomness(targets_cpu, bd_targets_cpu, opt, self.transforms, getattr(opt, "sigma", (0.1, 1.0)))
         nb = rnd.num_bd
         # ---- host tables (train_generator.py:181-204: batch order [poisoned, rest of target class, others])
-        trg = (targets_cpu == bd_targets_cpu).nonzero()[:, 0]
-        ntrg = (targets_cpu != bd_targets_cpu).nonzero()[:, 0]
-        perm = torch.cat([trg, ntrg]).to(torch.int32)
+        perm, tot, idx_small, idx_total = poison_tables(targets_cpu, bd_targets_cpu, nb)
         self.h_targets[0].copy_(targets_cpu)
         self.h_targets[1].copy_(bd_targets_cpu)
-        tot = targets_cpu[perm.long()].clone()
-        tot[:nb] = bd_targets_cpu[perm[:nb].long()]
         self.h_targets[2].copy_(tot)
-        idx_small, idx_total = self.h_tab_i[0], self.h_tab_i[1]
-        idx_small.zero_()
-        idx_small[:nb] = perm[:nb]
-        idx_total.copy_(perm)
-        if nb:
-            idx_total[:nb] = torch.arange(n, n + nb, dtype=torch.int32)
+        self.h_tab_i[0].copy_(idx_small)
+        self.h_tab_i[1].copy_(idx_total)
         aug_ptr = []
         for i, a in enumerate(rnd.aug):
             if a is not None:
@@ -215,8 +245,7 @@ class AlternatedStep:
         ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(), aug_ptr[0], n, hw,
                                          eC.input(self.sC_train).data_ptr(), None, st), "augment 0")
         pl["C_train_f"].run(prof)
-        pl["C_train_b"].run(prof)
-        self._allreduce(eC)
+        self._backward_allreduce(pl["C_train_b"], eC, prof)
         eC.fp.sgd_step(float(lr_c if lr_c is not None else opt.lr_C), grad_scale=1.0 / self.world)
         eC.mark_weights_dirty()
         eC.refresh()                       # re-pack bf16 operands, fold the new running stats
@@ -253,8 +282,7 @@ class AlternatedStep:
         l2_scale = float(opt.L2_weight) / float(n * 3 * hw * hw)          # :234, :253
         ops.check(lib.combat_trigger_bwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.d_bd.data_ptr(), bd_ptr,
                                          l2_scale, 1, self.sG.buf("g.z", (n, hw, hw, 8)).data_ptr(), st), "trigger bwd")
-        pl["G_b"].run(prof)
-        self._allreduce(eG)
+        self._backward_allreduce(pl["G_b"], eG, prof)
         eG.fp.sgd_step(float(lr_g if lr_g is not None else opt.lr_G), grad_scale=1.0 / self.world)
         eG.mark_weights_dirty()
         # ---- logged-only terms (:234-243)
@@ -271,37 +299,162 @@ class AlternatedStep:
         return F.mse_loss(e[:, :, 1:] - e[:, :, :-1], eb[:, :, 1:] - eb[:, :, :-1]) + \
             F.mse_loss(e[:, :, :, 1:] - e[:, :, :, :-1], eb[:, :, :, 1:] - eb[:, :, :, :-1])
 
-    def _allreduce(self, eng) -> None:
-        if self.world > 1:
-            torch.distributed.all_reduce(eng.fp.grad, group=self.pg)
+    def _backward_allreduce(self, plan, eng, prof) -> None:
+        """Run a backward plan; with several ranks, all-reduce the flat gradient buffer in buckets,
+        each launched as soon as the plan has enqueued the kernels that complete it."""
+        if self.world == 1:
+            plan.run(prof)
+            return
+        red = self._reducers.get(id(plan))
+        if red is None:
+            ranges = bucket_ranges(eng.fp.total, plan.marks.values())
+            red = (GradReducer(eng.fp.grad, ranges, self.pg), ranges)
+            self._reducers[id(plan)] = red
+        reducer, ranges = red
+        launched = set()
+
+        def on_mark(offset):
+            for i, (lo, hi) in enumerate(ranges):
+                if lo >= offset and i not in launched:
+                    launched.add(i)
+                    reducer.launch(i)
+
+        plan.run(prof, on_mark=on_mark)
+        on_mark(0)
+        reducer.wait()
 
     # ------------------------------------------------------------------ metrics
+    def _slot_sets(self):
+        """(sC_train, sC_clean, sC_bd, sK_clean, sK_bd) of every batch size seen so far."""
+        names = ("sC_train", "sC_clean", "sC_bd", "sK_clean", "sK_bd")
+        out = [tuple(getattr(self, k) for k in names)] if self.N else []
+        out += [tuple(d[k] for k in names) for n, d in self._sets.items() if n != self.N]
+        return out
+
     def read_metrics(self, reset: bool = False) -> Dict[str, float]:
-        """One host sync: the running sums the reference prints each step (:257-290)."""
-        hb = lambda eng, slot: eng.head_bufs(slot)
-        cC, cCl, cBd = hb(self.eC, self.sC_train), hb(self.eC, self.sC_clean), hb(self.eC, self.sC_bd)
-        kCl, kBd = hb(self.eK, self.sK_clean), hb(self.eK, self.sK_bd)
+        """One host sync: the running sums the reference prints each step (:257-290), over every
+        batch size run since the last reset."""
         acc = self.acc.cpu()
         total = max(float(acc[7]), 1.0)
         w_cm = float(self.opt.clean_model_weight) or 1.0
-        out = {
-            "samples": total,
-            "loss_c_sum": float(cC["loss"]), "loss_ce_sum": float(cBd["loss"]),
-            "clean_model_loss_sum": float(kBd["loss"]) / w_cm,
-            "loss_l2_sum": float(acc[0]), "loss_grad_l2_sum": float(acc[1]),
-            "clean_correct": int(cCl["correct"][0]), "bd_correct": int(cBd["correct"][0]),
-            "f_correct": int(acc[4]), "clean_model_correct": int(kCl["correct"][0]),
-            "clean_model_bd_ba": int(kBd["correct"][0]), "clean_model_bd_asr": int(kBd["correct"][1]),
-            "train_correct": int(cC["correct"][0]),
-        }
+        out = {"samples": total, "loss_c_sum": 0.0, "loss_ce_sum": 0.0, "clean_model_loss_sum": 0.0,
+               "loss_l2_sum": float(acc[0]), "loss_grad_l2_sum": float(acc[1]), "clean_correct": 0, "bd_correct": 0,
+               "f_correct": int(acc[4]), "clean_model_correct": 0, "clean_model_bd_ba": 0, "clean_model_bd_asr": 0,
+               "train_correct": 0}
+        for sCt, sCc, sCb, sKc, sKb in self._slot_sets():
+            cC, cCl, cBd = self.eC.head_bufs(sCt), self.eC.head_bufs(sCc), self.eC.head_bufs(sCb)
+            kCl, kBd = self.eK.head_bufs(sKc), self.eK.head_bufs(sKb)
+            out["loss_c_sum"] += float(cC["loss"])
+            out["loss_ce_sum"] += float(cBd["loss"])
+            out["clean_model_loss_sum"] += float(kBd["loss"]) / w_cm
+            out["clean_correct"] += int(cCl["correct"][0])
+            out["bd_correct"] += int(cBd["correct"][0])
+            out["clean_model_correct"] += int(kCl["correct"][0])
+            out["clean_model_bd_ba"] += int(kBd["correct"][0])
+            out["clean_model_bd_asr"] += int(kBd["correct"][1])
+            out["train_correct"] += int(cC["correct"][0])
         if reset:
             self.reset_metrics()
         return out
 
     def reset_metrics(self) -> None:
         self.acc.zero_()
-        for eng, slot in ((self.eC, self.sC_train), (self.eC, self.sC_clean), (self.eC, self.sC_bd),
-                          (self.eK, self.sK_clean), (self.eK, self.sK_bd)):
-            h = eng.head_bufs(slot)
+        for sCt, sCc, sCb, sKc, sKb in self._slot_sets():
+            for eng, slot in ((self.eC, sCt), (self.eC, sCc), (self.eC, sCb), (self.eK, sKc), (self.eK, sKb)):
+                h = eng.head_bufs(slot)
+                h["loss"].zero_()
+                h["correct"].zero_()
+
+
+class ClassifierStep:
+    """Phase-C-only training step: the loop bodies of train_clean_classifier.py:75-121 (no generator) and
+    train_victim.py:102-141 (frozen generator poisons the images the dataset flags).  Batch order as in
+    the victim script: [poisoned images with the trigger, all other images] (:125-127)."""
+
+    def __init__(self, netC, opt, netG=None, process_group=None):
+        self.opt, self.netC, self.netG = opt, netC, netG
+        self.dev = next(netC.parameters()).device
+        self.eC: PreActEngine = netC._net_engine()
+        self.eG: Optional[UnetEngine] = netG._net_engine() if netG is not None else None
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.hw = opt.input_height
+        self.P = trigger.lowpass_matrix(self.hw, opt.ratio).to(self.dev)
+        self.k1 = torch.zeros(3, dtype=f32, device=self.dev)
+        self.transforms = PostTensorTransform(opt)
+        self.N = 0
+        self._small: Dict[int, tuple] = {}
+        self._reducer = None
+
+    def _setup(self, n):
+        if n == self.N:
+            return
+        self.N, hw, dev = n, self.hw, self.dev
+        self.cat_src = torch.zeros(2 * n, 3, hw, hw, dtype=f32, device=dev)
+        self.tab_i = torch.zeros(2, n, dtype=torch.int32, device=dev)
+        self.tab_f = torch.zeros(n, 4, dtype=f32, device=dev)
+        self.slot = self.eC.slot("V.train", n, hw)
+        self.fwd = self.eC.forward_plan(self.slot, True)
+        self.bwd = self.eC.backward_train_plan(self.slot)
+
+    def run(self, inputs: torch.Tensor, targets_cpu: torch.Tensor, poisoned_cpu: Optional[torch.Tensor] = None,
+            lr: Optional[float] = None) -> None:
+        opt = self.opt
+        n = inputs.shape[0]
+        self._setup(n)
+        hw, st = self.hw, torch.cuda.current_stream().cuda_stream
+        targets_cpu = targets_cpu.cpu()
+        if poisoned_cpu is None or self.eG is None:
+            poisoned_cpu = torch.zeros(n, dtype=torch.bool)
+        trg = poisoned_cpu.cpu().nonzero()[:, 0]
+        ntrg = (~poisoned_cpu.cpu()).nonzero()[:, 0]      # intent of train_victim.py:121 (SURVEY D3)
+        nb = int(trg.numel())
+        perm = torch.cat([trg, ntrg]).to(torch.int32)
+        tot = targets_cpu[perm.long()].clone()
+        if nb:
+            tot[:nb] = create_targets_bd(targets_cpu[trg], opt)
+        idx = torch.zeros(2, n, dtype=torch.int32)
+        idx[0, :nb] = perm[:nb]
+        idx[1] = perm
+        if nb:
+            idx[1, :nb] = torch.arange(n, n + nb, dtype=torch.int32)
+        self.tab_i.copy_(idx)
+        aug = self.transforms.sample(n)
+        if aug is not None:
+            self.tab_f.copy_(torch.from_numpy(aug))
+        self.cat_src[:n].copy_(inputs)
+        h = self.eC.head_bufs(self.slot)
+        h["targets"].copy_(tot)
+        self.eC.refresh()
+        if nb:
+            self.eG.refresh()
+            nbk = min(bucket(nb), n)
+            if nbk not in self._small:
+                s = self.eG.slot("V.small", nbk, hw)
+                self._small[nbk] = (s, self.eG.forward_plan(s), torch.zeros(nbk, 3, hw, hw, dtype=f32, device=self.dev))
+            sS, plan_small, tochange = self._small[nbk]
+            self.k1.copy_(torch.from_numpy(trigger.gaussian_kernel1d(
+                trigger.sample_sigma(getattr(opt, "sigma", (0.1, 1.0))), opt.kernel_size)))
+            ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[0].data_ptr(), None, nbk, hw,
+                                             self.eG.input(sS).data_ptr(), tochange.data_ptr(), st), "gather poisoned")
+            plan_small.run()
+            ops.check(lib.combat_trigger_fwd(tochange.data_ptr(), self.eG.output(sS).data_ptr(), self.P.data_ptr(),
+                                             self.k1.data_ptr(), float(opt.noise_rate), nb, hw,
+                                             self.cat_src[n:].data_ptr(), None, None, st), "trigger")
+        ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(),
+                                         self.tab_f.data_ptr() if aug is not None else None, n, hw,
+                                         self.eC.input(self.slot).data_ptr(), None, st), "augment")
+        self.fwd.run()
+        self.bwd.run()
+        if self.world > 1:
+            torch.distributed.all_reduce(self.eC.fp.grad, group=self.pg)
+        self.eC.fp.sgd_step(float(lr if lr is not None else opt.lr_C), grad_scale=1.0 / self.world)
+        self.eC.mark_weights_dirty()
+
+    def read_metrics(self, reset=False):
+        h = self.eC.head_bufs(self.slot)
+        out = {"loss_sum": float(h["loss"]), "correct": int(h["correct"][0])}
+        if reset:
             h["loss"].zero_()
             h["correct"].zero_()
+        return out

@@ -302,6 +302,27 @@ def golden_step():
     save("step.npz", out)
 
 
+def golden_config():
+    """Flag names, defaults and types of the reference parser (config.py:4-86)."""
+    import json
+    sys.modules.pop("config", None)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_config", os.path.join(REF, "config.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    flags = {}
+    for a in mod.get_arguments()._actions:
+        if a.dest == "help":
+            continue
+        d = a.default
+        flags[a.dest] = {"default": list(d) if isinstance(d, (list, tuple)) else d,
+                         "type": getattr(a.type, "__name__", None), "choices": a.choices,
+                         "store_true": a.nargs == 0}
+    with open(os.path.join(HERE, "config_flags.json"), "w") as f:
+        json.dump(flags, f, indent=1, sort_keys=True)
+    print("wrote config_flags.json (%d flags)" % len(flags))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     golden_dct()
@@ -310,3 +331,4 @@ if __name__ == "__main__":
     golden_resnet()
     golden_freq()
     golden_step()
+    golden_config()

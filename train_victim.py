@@ -1,0 +1,120 @@
+"""Victim training on data poisoned by the frozen generator (reference train_victim.py:93-165 loop,
+:168-231 eval, :221-229 checkpoint keys; dataset flags from utils/dataloader_cleanbd.py:131-158)."""
+import os
+import shutil
+
+import torch
+
+import config
+from combat_amd import api, dist as cdist
+from combat_amd.data import get_dataloader
+from combat_amd.log import SummaryWriter, progress_bar
+from combat_amd.nets import PreActResNet18, UnetGenerator
+from combat_amd.step import ClassifierStep, create_targets_bd
+
+
+def get_model(opt):
+    if opt.dataset != "cifar10" or opt.model != "default":
+        raise Exception("only cifar10 / PreActResNet18 run on the HIP path this round")
+    netC = PreActResNet18().to(opt.device)
+    netG = UnetGenerator(opt).to(opt.device)
+    optimizerC = torch.optim.SGD(netC.parameters(), opt.lr_C, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    schedulerC = torch.optim.lr_scheduler.MultiStepLR(optimizerC, opt.schedulerC_milestones, opt.schedulerC_lambda)
+    return netC, optimizerC, schedulerC, netG
+
+
+def train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt):
+    print(" Train:")
+    netC.train()
+    step = netC.__dict__.setdefault("_clf_step", ClassifierStep(netC, opt, netG))
+    if step.N:
+        step.read_metrics(reset=True)
+    total = 0
+    for batch_idx, (inputs, targets, poisoned) in enumerate(train_dl):
+        step.run(inputs.to(opt.device, non_blocking=True), targets, poisoned, lr=optimizerC.param_groups[0]["lr"])
+        total += inputs.shape[0]
+        last = batch_idx == len(train_dl) - 1 or (opt.max_steps and batch_idx + 1 >= opt.max_steps)
+        if batch_idx % max(1, opt.log_interval) == 0 or last:
+            m = step.read_metrics()
+            progress_bar(batch_idx, len(train_dl), "CE Loss: {:.4f} | Clean Acc: {:.4f}".format(
+                m["loss_sum"] / total, m["correct"] * 100.0 / total))
+        if last:
+            break
+    tf_writer.add_scalars("Clean Accuracy", {"Clean": m["correct"] * 100.0 / total}, epoch)
+    schedulerC.step()
+
+
+def eval(netC, optimizerC, schedulerC, netG, test_dl, best_clean_acc, best_bd_acc, tf_writer, epoch, opt):
+    print(" Eval:")
+    netC.eval()
+    n = nb = correct = bd = 0
+    for batch_idx, batch in enumerate(test_dl):
+        inputs, targets = batch[0].to(opt.device), batch[1].to(opt.device)
+        with torch.no_grad():
+            correct += int((netC(inputs).argmax(1) == targets).sum())
+            n += len(inputs)
+            ntrg = (targets != opt.target_label).nonzero()[:, 0]
+            if len(ntrg):
+                inputs_bd = api.create_backdoor(netG, inputs[ntrg], opt)
+                targets_bd = create_targets_bd(targets[ntrg], opt).to(opt.device)
+                bd += int((netC(inputs_bd).argmax(1) == targets_bd).sum())
+                nb += len(ntrg)
+        acc_clean, acc_bd = correct * 100.0 / n, bd * 100.0 / max(nb, 1)
+        progress_bar(batch_idx, len(test_dl), "Clean Acc: {:.4f} - Best: {:.4f} | Bd Acc: {:.4f} - Best: {:.4f}".format(
+            acc_clean, best_clean_acc, acc_bd, best_bd_acc))
+    tf_writer.add_scalars("Test Accuracy", {"Clean": acc_clean, "Bd": acc_bd}, epoch)
+    if acc_clean > best_clean_acc:
+        print(" Saving...")
+        best_clean_acc, best_bd_acc = acc_clean, acc_bd
+        api.sync_momentum_to_optimizer(optimizerC, netC)
+        torch.save({"netC": netC.state_dict(), "schedulerC": schedulerC.state_dict(), "optimizerC": optimizerC.state_dict(),
+                    "netG": netG.state_dict(), "best_clean_acc": acc_clean, "best_bd_acc": acc_bd, "epoch_current": epoch},
+                   opt.ckpt_path)
+    return best_clean_acc, best_bd_acc
+
+
+def main():
+    opt = config.get_arguments().parse_args()
+    if opt.dataset != "cifar10":
+        raise Exception("Invalid Dataset")
+    opt.input_height, opt.input_width, opt.input_channel = 32, 32, 3
+    rank, local_rank, world = cdist.init()
+    if opt.device == "cuda":
+        opt.device = "cuda:%d" % local_rank
+    train_dl = get_dataloader(opt, True, poisoned=True)
+    test_dl = get_dataloader(opt, False, shuffle=False, poisoned=True)
+    netC, optimizerC, schedulerC, netG = get_model(opt)
+    mode = opt.saving_prefix
+    opt.ckpt_folder = os.path.join(opt.checkpoints, mode, opt.dataset)
+    opt.ckpt_path = os.path.join(opt.ckpt_folder, "{}_{}.pth.tar".format(opt.dataset, mode))
+    opt.log_dir = os.path.join(opt.ckpt_folder, "log_dir")
+    load_path = os.path.join(opt.checkpoints, opt.load_checkpoint, opt.dataset,
+                             "{}_{}.pth.tar".format(opt.dataset, opt.load_checkpoint))
+    if not os.path.exists(load_path):
+        print("Error: {} not found".format(load_path))
+        exit()
+    netG.load_state_dict(torch.load(load_path, map_location=opt.device, weights_only=False)["netG"])
+    netG.eval()
+    netG.requires_grad_(False)      # :279-280
+    best_clean_acc = best_bd_acc = 0.0
+    epoch_current = 0
+    if opt.continue_training and os.path.exists(opt.ckpt_path):
+        sd = torch.load(opt.ckpt_path, map_location=opt.device, weights_only=False)
+        netC.load_state_dict(sd["netC"])
+        optimizerC.load_state_dict(sd["optimizerC"])
+        schedulerC.load_state_dict(sd["schedulerC"])
+        api.load_momentum_from_optimizer(optimizerC, netC)
+        best_clean_acc, best_bd_acc, epoch_current = sd["best_clean_acc"], sd["best_bd_acc"], sd["epoch_current"]
+    else:
+        shutil.rmtree(opt.ckpt_folder, ignore_errors=True)
+    os.makedirs(opt.log_dir, exist_ok=True)
+    tf_writer = SummaryWriter(log_dir=opt.log_dir)
+    for epoch in range(epoch_current, opt.n_iters):
+        print("Epoch {}:".format(epoch + 1))
+        train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt)
+        best_clean_acc, best_bd_acc = eval(netC, optimizerC, schedulerC, netG, test_dl, best_clean_acc, best_bd_acc,
+                                           tf_writer, epoch, opt)
+
+
+if __name__ == "__main__":
+    main()
