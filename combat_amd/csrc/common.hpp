@@ -41,6 +41,26 @@ __device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
     v[7] = bf16_bits_to_f32(u.w >> 16);
 }
 
+__device__ __forceinline__ void unpack8v(const u32x4_t &u, float (&v)[8]) {
+    v[0] = bf16_bits_to_f32(u[0] & 0xffffu);
+    v[1] = bf16_bits_to_f32(u[0] >> 16);
+    v[2] = bf16_bits_to_f32(u[1] & 0xffffu);
+    v[3] = bf16_bits_to_f32(u[1] >> 16);
+    v[4] = bf16_bits_to_f32(u[2] & 0xffffu);
+    v[5] = bf16_bits_to_f32(u[2] >> 16);
+    v[6] = bf16_bits_to_f32(u[3] & 0xffffu);
+    v[7] = bf16_bits_to_f32(u[3] >> 16);
+}
+
+__device__ __forceinline__ u32x4_t pack8v(const float (&v)[8]) {
+    u32x4_t u;
+    u[0] = pack_bf16x2(v[0], v[1]);
+    u[1] = pack_bf16x2(v[2], v[3]);
+    u[2] = pack_bf16x2(v[4], v[5]);
+    u[3] = pack_bf16x2(v[6], v[7]);
+    return u;
+}
+
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     uint4 u;
     u.x = pack_bf16x2(v[0], v[1]);

@@ -175,25 +175,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < T::FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // all fragments of the 64-deep step are fetched before its MFMAs and the order is pinned: the
+    // compiler otherwise interleaves one ds_read + s_waitcnt lgkmcnt(0) per few MFMAs (an exposed LDS
+    // round trip each time, see conv3x3.hip)
     auto compute = [&](int buf) {
         const unsigned char *al = smem + buf * (BM * 128);
         const unsigned char *bl = smem + 2 * (BM * 128) + buf * (BN * 128);
         const int fr = lane & 15, fq = lane >> 4;
+        bf16x8_t pix[2][T::FM], wts[2][T::FN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t pix[T::FM], wts[T::FN];
 #pragma unroll
             for (int j = 0; j < T::FM; ++j)
-                pix[j] = *reinterpret_cast<const bf16x8_t *>(al + lds_off(wave_m * T::WM + j * 16 + fr, ks * 4 + fq));
+                pix[ks][j] = *reinterpret_cast<const bf16x8_t *>(al + lds_off(wave_m * T::WM + j * 16 + fr, ks * 4 + fq));
 #pragma unroll
             for (int i = 0; i < T::FN; ++i)
-                wts[i] = *reinterpret_cast<const bf16x8_t *>(bl + lds_off(wave_n * T::WN + i * 16 + fr, ks * 4 + fq));
+                wts[ks][i] = *reinterpret_cast<const bf16x8_t *>(bl + lds_off(wave_n * T::WN + i * 16 + fr, ks * 4 + fq));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < T::FN; ++i)
 #pragma unroll
                 for (int j = 0; j < T::FM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wts[i], pix[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wts[ks][i], pix[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     // ---- main loop

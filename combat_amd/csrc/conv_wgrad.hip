@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int C = a.C, K = a.K, H = a.H, W = a.W;
     const bool pro_affine = a.pro_scale != nullptr;
 
-    uint4 rk[T::ITK], rc[T::ITC];
+    u32x4_t rk[T::ITK];
+    uint4 rc[T::ITC];
     unsigned vc = 0;
     int gc[T::ITC];
 
@@ -84,8 +85,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             const int idx = tid + 256 * i;
             const int row = idx / T::CHK, ch = idx % T::CHK;
             const int m = mt + row, n = k0 + ch * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (idx < 64 * T::CHK && m < m_end && n < K) v = *reinterpret_cast<const uint4 *>(dy + (size_t)m * K + n);
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (idx < 64 * T::CHK && m < m_end && n < K) v = *reinterpret_cast<const u32x4_t *>(dy + (size_t)m * K + n);
             rk[i] = v;
         }
         vc = 0;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             const int idx = tid + 256 * i;
             if (idx < 64 * T::CHK) {
                 const int row = idx / T::CHK, ch = idx % T::CHK;
-                *reinterpret_cast<uint4 *>(kl + row * T::SK + ch * 16) = rk[i];
+                *reinterpret_cast<u32x4_t *>(kl + row * T::SK + ch * 16) = rk[i];
             }
         }
 #pragma unroll
@@ -158,34 +159,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         const unsigned char *kl = smem + buf * T::BUF;
         const unsigned char *cl = kl + 64 * T::SK;
         // transposing read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a
-        // 4(pixel) x 16(channel) block and receives the 4 pixels of channel (lane & 15)
+        // 4(pixel) x 16(channel) block and receives the 4 pixels of channel (lane & 15).
+        // All fragments of the 64-pixel step first, then the MFMAs (order pinned, see conv3x3.hip).
         const int q = (lane & 15) >> 2, pp = lane & 3, fq = lane >> 4;
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        bf16x8_t fk[2][T::FK], fc[2][T::FC];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int prow = ks * 32 + fq * 8 + q;
-            bf16x8_t fk[T::FK], fc[T::FC];
 #pragma unroll
             for (int i = 0; i < T::FK; ++i) {
                 const unsigned char *b = kl + prow * T::SK + (wave_k * T::WK + i * 16 + pp * 4) * 2;
                 const s16x4_t lo = lds_tr16(b), hi = lds_tr16(b + 4 * T::SK);
-                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
                 const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                fk[i] = __builtin_bit_cast(bf16x8_t, v);
+                fk[ks][i] = __builtin_bit_cast(bf16x8_t, v);
             }
 #pragma unroll
             for (int j = 0; j < T::FC; ++j) {
                 const unsigned char *b = cl + prow * T::SC + (wave_c * T::WC + j * 16 + pp * 4) * 2;
                 const s16x4_t lo = lds_tr16(b), hi = lds_tr16(b + 4 * T::SC);
-                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
                 const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                fc[j] = __builtin_bit_cast(bf16x8_t, v);
+                fc[ks][j] = __builtin_bit_cast(bf16x8_t, v);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < T::FK; ++i)
 #pragma unroll
                 for (int j = 0; j < T::FC; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[i], fc[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[ks][i], fc[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     load_tile(0);

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ 
     float s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    for (long r = threadIdx.x; r < rows; r += 256) {
+    for (long r = (long)blockIdx.y * 256 + threadIdx.x; r < rows; r += 256L * gridDim.y) {
         float v[8];
         unpack8(*reinterpret_cast<const uint4 *>(x + r * C + c), v);
 #pragma unroll
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ 
         }
         __syncthreads();
     }
-    if (threadIdx.x < 8 && c + (int)threadIdx.x < c_out) out[c + threadIdx.x] = sh[0][threadIdx.x];
+    if (threadIdx.x < 8 && c + (int)threadIdx.x < c_out) atomicAdd(out + c + threadIdx.x, sh[0][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ max pool / ELU+affine
@@ -375,7 +375,11 @@ extern "C" int combat_memset_zero(void *ptr, int64_t bytes, void *stream) {
 
 extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream) {
     if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || c_out <= 0 || c_out > C) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3((c_out + 7) / 8), dim3(256), 0, as_stream(stream),
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(out, 0, sizeof(float) * c_out, st) != hipSuccess) return COMBAT_ELAUNCH;
+    long ysplit = (rows + 2047) / 2048;   // ~8 rows per thread
+    if (ysplit > 512) ysplit = 512;
+    hipLaunchKernelGGL(colsum_kernel, dim3((c_out + 7) / 8, (unsigned)ysplit), dim3(256), 0, st,
                        reinterpret_cast<const __bf16 *>(x), (long)rows, C, c_out, out);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -428,7 +432,7 @@ extern "C" int combat_sgd_nesterov(const void *ptrs, const int64_t *sizes, int32
                                    void *stream) {
     if (!ptrs || !sizes || count <= 0 || max_size <= 0) return COMBAT_EINVAL;
     long bx = (max_size + 255) / 256;
-    if (bx > 256) bx = 256;
+    if (bx > 4096) bx = 4096;
     hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<void *const *>(ptrs), sizes, lr, momentum, weight_decay, grad_scale, first_step);
     CB_LAUNCH_CHECK();
