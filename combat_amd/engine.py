@@ -83,6 +83,17 @@ class Slot:
         self.norm: Dict[str, "NormState"] = {}
         self.plans: Dict[str, Plan] = {}
 
+    def half_view(self, lo: int, n: int, share: Tuple[str, ...]) -> "Slot":
+        """A slot over images [lo, lo+n) of this one: the named buffers are views (batch-major
+        layouts make any image range contiguous), everything else is allocated on demand.  Used to run
+        the backward of only the triggered half of a merged eval forward."""
+        s = Slot(self.device, n, self.hw)
+        for k in share:
+            if k in self.bufs:
+                s.bufs[k] = self.bufs[k][lo:lo + n]
+        s.feat_hw = getattr(self, "feat_hw", None)
+        return s
+
     def buf(self, name: str, shape, dtype=bf16, zero: bool = False) -> torch.Tensor:
         t = self.bufs.get(name)
         if t is None:
@@ -406,8 +417,15 @@ class PreActEngine(NetEngine):
     def input(self, slot: Slot) -> torch.Tensor:
         return slot.buf("x", (slot.N, slot.hw, slot.hw, 8))
 
-    def forward_plan(self, slot: Slot, train: bool, loss_weight: float = 1.0, with_targets2: bool = False) -> Plan:
-        key = "fwd.%s.%g.%d" % ("train" if train else "eval", loss_weight, with_targets2)
+    FWD_SHARED = ("stem", "logits", "dlogits", "pooled", "targets", "targets2") + tuple(
+        "b%d.%s" % (b, s) for b in range(8) for s in ("y1", "out", "sc"))
+
+    def forward_plan(self, slot: Slot, train: bool, loss_weight: float = 1.0, with_targets2: bool = False,
+                     split_head: bool = False) -> Plan:
+        """split_head (eval only): the batch is two independent halves [metric-only images ; images whose
+        loss is differentiated]; the head runs once per half with separate loss / counter cells
+        (first half -> correct[0] of slot 'loss0/correct0' cells, second half -> the usual ones)."""
+        key = "fwd.%s.%g.%d.%d" % ("train" if train else "eval", loss_weight, with_targets2, split_head)
         if key in slot.plans:
             return slot.plans[key]
         P = Plan("preact." + key)
@@ -450,11 +468,28 @@ class PreActEngine(NetEngine):
             cur, chw = out, ohw
         h = self.head_bufs(slot)
         P.hold(h)
-        P.add("head", lib.combat_head_fwd, cur.data_ptr(), n, chw, cur.shape[-1], self.lin_w.data_ptr(),
-              self.lin_b.data_ptr(), self.classes, h["targets"].data_ptr(), loss_weight, h["pooled"].data_ptr(),
-              h["logits"].data_ptr(), h["loss"].data_ptr(), h["correct"].data_ptr(),
-              h["targets2"].data_ptr() if with_targets2 else None,
-              h["correct"][1:].data_ptr() if with_targets2 else None)
+        if not split_head:
+            P.add("head", lib.combat_head_fwd, cur.data_ptr(), n, chw, cur.shape[-1], self.lin_w.data_ptr(),
+                  self.lin_b.data_ptr(), self.classes, h["targets"].data_ptr(), loss_weight, h["pooled"].data_ptr(),
+                  h["logits"].data_ptr(), h["loss"].data_ptr(), h["correct"].data_ptr(),
+                  h["targets2"].data_ptr() if with_targets2 else None,
+                  h["correct"][1:].data_ptr() if with_targets2 else None)
+        else:
+            assert not train and n % 2 == 0
+            m = n // 2
+            loss0 = slot.buf("loss0", (1,), f32, zero=True)
+            correct0 = slot.buf("correct0", (2,), torch.int32, zero=True)
+            views = [cur[:m], cur[m:], h["targets"][:m], h["targets"][m:], h["pooled"][:m], h["pooled"][m:],
+                     h["logits"][:m], h["logits"][m:], h["targets2"][m:]]
+            P.hold(views, loss0, correct0)
+            P.add("head.metric", lib.combat_head_fwd, views[0].data_ptr(), m, chw, cur.shape[-1], self.lin_w.data_ptr(),
+                  self.lin_b.data_ptr(), self.classes, views[2].data_ptr(), 1.0, views[4].data_ptr(),
+                  views[6].data_ptr(), loss0.data_ptr(), correct0.data_ptr(), None, None)
+            P.add("head.loss", lib.combat_head_fwd, views[1].data_ptr(), m, chw, cur.shape[-1], self.lin_w.data_ptr(),
+                  self.lin_b.data_ptr(), self.classes, views[3].data_ptr(), loss_weight, views[5].data_ptr(),
+                  views[7].data_ptr(), h["loss"].data_ptr(), h["correct"].data_ptr(),
+                  views[8].data_ptr() if with_targets2 else None,
+                  h["correct"][1:].data_ptr() if with_targets2 else None)
         slot.plans[key] = P
         slot.feat_hw = chw
         return P

@@ -124,7 +124,7 @@ class AlternatedStep:
 
     # ------------------------------------------------------------------ buffers per batch size
     _PER_N = ("inputs", "cat_src", "bd", "d_bd", "mse", "tab_f", "tab_i", "h_tab_f", "h_tab_i", "h_k1", "h_targets",
-              "d_targets", "sC_train", "sC_clean", "sC_bd", "sK_clean", "sK_bd", "sG", "sF", "pl", "_targets_of",
+              "d_targets", "sC_train", "sC_eval", "sC_bd", "sK_eval", "sK_bd", "sG", "sF", "pl", "_targets_of",
               "_gen_small")
 
     def _setup(self, n: int):
@@ -154,28 +154,32 @@ class AlternatedStep:
         self.h_targets = torch.zeros(3, n, dtype=torch.int64).pin_memory()    # targets, bd_targets, total_targets
         self.d_targets = torch.zeros(3, n, dtype=torch.int64, device=dev)
         eC, eK, eG = self.eC, self.eK, self.eG
+        # The eval-mode forwards of one network are independent per sample, so the metric-only forward
+        # and the differentiated one run as ONE 2n-image batch [aug(inputs) ; aug(inputs_bd)]
+        # (train_generator.py:227+228 for netC, :214+250 for clean_model -- clean_model is frozen and
+        # :214 reads only `inputs`, so running it in Phase G changes nothing); the backward covers
+        # the triggered half only, through a view slot.
         self.sC_train = eC.slot("C.train", n, hw)
-        self.sC_clean = eC.slot("C.clean", n, hw)
-        self.sC_bd = eC.slot("C.bd", n, hw)
-        self.sK_clean = eK.slot("K.clean", n, hw)
-        self.sK_bd = eK.slot("K.bd", n, hw)
+        self.sC_eval = eC.slot("C.eval2", 2 * n, hw)
+        self.sK_eval = eK.slot("K.eval2", 2 * n, hw)
         self.sG = eG.slot("G", n, hw)
         self.sF = self.eF.slot("F", n, hw) if self.eF is not None else None
         w_cm = float(self.opt.clean_model_weight)
         self.pl = dict(
             C_train_f=eC.forward_plan(self.sC_train, True), C_train_b=eC.backward_train_plan(self.sC_train),
-            C_clean_f=eC.forward_plan(self.sC_clean, False),
-            C_bd_f=eC.forward_plan(self.sC_bd, False), C_bd_b=eC.backward_eval_plan(self.sC_bd, 1.0),
-            K_clean_f=eK.forward_plan(self.sK_clean, False),
-            K_bd_f=eK.forward_plan(self.sK_bd, False, w_cm, True), K_bd_b=eK.backward_eval_plan(self.sK_bd, w_cm),
+            C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False, split_head=True),
+            K_eval_f=eK.forward_plan(self.sK_eval, False, w_cm, True, split_head=True),
             G_f=eG.forward_plan(self.sG), G_b=eG.backward_plan(self.sG),
         )
+        self.sC_bd = self.sC_eval.half_view(n, n, eC.FWD_SHARED)
+        self.sK_bd = self.sK_eval.half_view(n, n, eK.FWD_SHARED)
+        self.pl["C_bd_b"] = eC.backward_eval_plan(self.sC_bd, 1.0)
+        self.pl["K_bd_b"] = eK.backward_eval_plan(self.sK_bd, w_cm)
         if self.sF is not None:
             self.pl["F_f"] = self.eF.forward_plan(self.sF)
-        # targets live in the head buffers of each slot: point them at the shared table once
-        self._targets_of = {
-            "C.train": (self.sC_train, 2, None), "C.clean": (self.sC_clean, 0, None), "C.bd": (self.sC_bd, 1, None),
-            "K.clean": (self.sK_clean, 0, None), "K.bd": (self.sK_bd, 0, 1)}
+        # head targets: (slot, engine, rows of d_targets for [first half, second half], targets2 row)
+        self._targets_of = {"C.train": (self.sC_train, eC, (2,), None), "C.eval": (self.sC_eval, eC, (0, 1), None),
+                            "K.eval": (self.sK_eval, eK, (0, 0), 1)}
         self._gen_small: Dict[int, tuple] = {}
 
     def _small(self, nbk: int):
@@ -220,12 +224,12 @@ class AlternatedStep:
         self.d_targets.copy_(self.h_targets, non_blocking=True)
         self.inputs.copy_(inputs, non_blocking=True)
         self.cat_src[:n].copy_(self.inputs)
-        for name, (slot, ti, t2) in self._targets_of.items():
-            eng = self.eK if name.startswith("K") else self.eC
+        for name, (slot, eng, rows, t2) in self._targets_of.items():
             h = eng.head_bufs(slot)
-            h["targets"].copy_(self.d_targets[ti])
+            for i, r in enumerate(rows):
+                h["targets"][i * n:(i + 1) * n].copy_(self.d_targets[r])
             if t2 is not None:
-                h["targets2"].copy_(self.d_targets[t2])
+                h["targets2"][n:].copy_(self.d_targets[t2])
         eC, eG, eK, eF, pl = self.eC, self.eG, self.eK, self.eF, self.pl
         for e in (eC, eG, eK) + ((eF,) if eF is not None else ()):
             e.refresh()
@@ -249,9 +253,8 @@ class AlternatedStep:
         eC.fp.sgd_step(float(lr_c if lr_c is not None else opt.lr_C), grad_scale=1.0 / self.world)
         eC.mark_weights_dirty()
         eC.refresh()                       # re-pack bf16 operands, fold the new running stats
-        ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[1], n, hw, eK.input(self.sK_clean).data_ptr(), None, st),
-                  "augment 1")
-        pl["K_clean_f"].run(prof)              # :214 metric only
+        xK, xC = eK.input(self.sK_eval), eC.input(self.sC_eval)     # [2n, hw, hw, 8]: metric half, loss half
+        ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[1], n, hw, xK.data_ptr(), None, st), "augment 1")  # :214
 
         # ================= Phase G (train_generator.py:216-255) =================
         ops.check(lib.combat_image_to_c8(x_ptr, n, hw, eG.input(self.sG).data_ptr(), st), "c8 G")
@@ -260,12 +263,9 @@ class AlternatedStep:
         ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.bd.data_ptr(), None,
                                          self.mse.data_ptr(), st), "trigger G")
         bd_ptr = self.bd.data_ptr()
-        ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, eC.input(self.sC_clean).data_ptr(), None, st),
-                  "augment 2")
-        pl["C_clean_f"].run(prof)              # :227 metric only
-        ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, eC.input(self.sC_bd).data_ptr(), None, st),
-                  "augment 3")
-        pl["C_bd_f"].run(prof)                 # :228, :231
+        ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, xC.data_ptr(), None, st), "augment 2")   # :227
+        ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, xC[n:].data_ptr(), None, st), "augment 3")
+        pl["C_eval_f"].run(prof)               # :227 (metric half) + :228, :231 (loss half)
         pl["C_bd_b"].run(prof)
         ops.check(lib.combat_augment_bwd(self.sC_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[3], n, hw,
                                          self.d_bd.data_ptr(), 0, st), "augment 3 bwd")
@@ -273,9 +273,8 @@ class AlternatedStep:
             ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), st), "dct")
             pl["F_f"].run(prof)
             self.acc[4] += (self.sF.bufs["logits"].argmax(1) == 1).sum()
-        ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[4], n, hw, eK.input(self.sK_bd).data_ptr(), None, st),
-                  "augment 4")
-        pl["K_bd_f"].run(prof)                 # :250-251
+        ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[4], n, hw, xK[n:].data_ptr(), None, st), "augment 4")
+        pl["K_eval_f"].run(prof)               # :214 (metric half) + :250-251 (loss half)
         pl["K_bd_b"].run(prof)
         ops.check(lib.combat_augment_bwd(self.sK_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[4], n, hw,
                                          self.d_bd.data_ptr(), 1, st), "augment 4 bwd")
@@ -325,8 +324,8 @@ class AlternatedStep:
 
     # ------------------------------------------------------------------ metrics
     def _slot_sets(self):
-        """(sC_train, sC_clean, sC_bd, sK_clean, sK_bd) of every batch size seen so far."""
-        names = ("sC_train", "sC_clean", "sC_bd", "sK_clean", "sK_bd")
+        """(sC_train, sC_eval, sK_eval) of every batch size seen so far."""
+        names = ("sC_train", "sC_eval", "sK_eval")
         out = [tuple(getattr(self, k) for k in names)] if self.N else []
         out += [tuple(d[k] for k in names) for n, d in self._sets.items() if n != self.N]
         return out
@@ -341,17 +340,16 @@ class AlternatedStep:
                "loss_l2_sum": float(acc[0]), "loss_grad_l2_sum": float(acc[1]), "clean_correct": 0, "bd_correct": 0,
                "f_correct": int(acc[4]), "clean_model_correct": 0, "clean_model_bd_ba": 0, "clean_model_bd_asr": 0,
                "train_correct": 0}
-        for sCt, sCc, sCb, sKc, sKb in self._slot_sets():
-            cC, cCl, cBd = self.eC.head_bufs(sCt), self.eC.head_bufs(sCc), self.eC.head_bufs(sCb)
-            kCl, kBd = self.eK.head_bufs(sKc), self.eK.head_bufs(sKb)
+        for sCt, sCe, sKe in self._slot_sets():
+            cC, cE, kE = self.eC.head_bufs(sCt), self.eC.head_bufs(sCe), self.eK.head_bufs(sKe)
             out["loss_c_sum"] += float(cC["loss"])
-            out["loss_ce_sum"] += float(cBd["loss"])
-            out["clean_model_loss_sum"] += float(kBd["loss"]) / w_cm
-            out["clean_correct"] += int(cCl["correct"][0])
-            out["bd_correct"] += int(cBd["correct"][0])
-            out["clean_model_correct"] += int(kCl["correct"][0])
-            out["clean_model_bd_ba"] += int(kBd["correct"][0])
-            out["clean_model_bd_asr"] += int(kBd["correct"][1])
+            out["loss_ce_sum"] += float(cE["loss"])
+            out["clean_model_loss_sum"] += float(kE["loss"]) / w_cm
+            out["clean_correct"] += int(sCe.bufs["correct0"][0])
+            out["bd_correct"] += int(cE["correct"][0])
+            out["clean_model_correct"] += int(sKe.bufs["correct0"][0])
+            out["clean_model_bd_ba"] += int(kE["correct"][0])
+            out["clean_model_bd_asr"] += int(kE["correct"][1])
             out["train_correct"] += int(cC["correct"][0])
         if reset:
             self.reset_metrics()
@@ -359,11 +357,14 @@ class AlternatedStep:
 
     def reset_metrics(self) -> None:
         self.acc.zero_()
-        for sCt, sCc, sCb, sKc, sKb in self._slot_sets():
-            for eng, slot in ((self.eC, sCt), (self.eC, sCc), (self.eC, sCb), (self.eK, sKc), (self.eK, sKb)):
+        for sCt, sCe, sKe in self._slot_sets():
+            for eng, slot in ((self.eC, sCt), (self.eC, sCe), (self.eK, sKe)):
                 h = eng.head_bufs(slot)
                 h["loss"].zero_()
                 h["correct"].zero_()
+                for k in ("loss0", "correct0"):
+                    if k in slot.bufs:
+                        slot.bufs[k].zero_()
 
 
 class ClassifierStep:
