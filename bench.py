@@ -32,7 +32,9 @@ sys.path.insert(0, ROOT)
 METRIC = "images/sec per alternated generator+surrogate step, CIFAR-10 bs=128, 1/2/4/8 GPU"
 PEAK_BF16_TFLOPS = 2500.0
 TILE_NAMES = {1: "conv_gemm_kernel<128,128>", 2: "conv_gemm_kernel<128,64>", 3: "conv_gemm_kernel<64,64>",
-              4: "conv_gemm_kernel<128,16>", 5: "conv_gemm_kernel<64,128>"}
+              4: "conv_gemm_kernel<128,16>", 5: "conv_gemm_kernel<64,128>",
+              6: "conv3x3_halo1_kernel<256,64>", 7: "conv3x3_halo1_kernel<128,128>", 8: "conv3x3_halo1_kernel<128,64>",
+              9: "conv3x3_halo_kernel<64,64>", 10: "conv3x3_dma_kernel<64>"}
 
 
 def log(msg):

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcombat_hip.so")
+LIB_PATH = os.environ.get("COMBAT_HIP_LIB") or os.path.join(HERE, "libcombat_hip.so")   # override: profiling builds
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -90,7 +90,7 @@ SIGNATURES = {
 }
 
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x16, TILE_64x128 = 1, 2, 3, 4, 5
-TILE_H256x64, TILE_H128x128, TILE_H128x64, TILE_H64x64 = 6, 7, 8, 9
+TILE_H256x64, TILE_H128x128, TILE_H128x64, TILE_H64x64, TILE_D128x64 = 6, 7, 8, 9, 10
 
 
 class CombatHipError(RuntimeError):

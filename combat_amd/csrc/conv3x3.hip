@@ -13,6 +13,22 @@
 // transposed weight pack.  Everything after the accumulators is the shared fused epilogue.
 #include "conv_common.hpp"
 
+// In-kernel phase stamps (profiling builds only: -DCOMBAT_STAMPS).  Thread 0 of every workgroup
+// writes the shader clock at phase boundaries to a buffer registered with combat_debug_set_stamps.
+#ifdef COMBAT_STAMPS
+__device__ unsigned long long *g_stamps;
+extern "C" int combat_debug_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &p, sizeof(p)); }
+#define STAMP(k)                                                                                         \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && g_stamps) {                                                              \
+            g_stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter();                              \
+            g_stamps[blockIdx.x * 16 + 8 + (k)] = wall_clock64();                                        \
+        }                                                                                                \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 namespace {
 
 constexpr int kRow = 160;  // bytes per LDS pixel / weight row (64 bf16 + pad)
@@ -46,8 +62,8 @@ __device__ __forceinline__ void halo1_store_w(const u32x4_t (&rw)[N], unsigned c
     for (int j = 0; j < N; ++j) *reinterpret_cast<u32x4_t *>(b + (w_row0 + 32 * j) * kRow + w_chunk * 16) = rw[j];
 }
 
-template <int BM, int BN, int WGM>
-__global__ __launch_bounds__(256) void conv3x3_halo1_kernel(const HaloParams p) {
+template <int BM, int BN, int WGM, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv3x3_halo1_kernel(const HaloParams p) {
     using T = TileCfg<BM, BN, WGM>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const combat_conv_args &a = p.a;
@@ -158,6 +174,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo1_kernel(const HaloParams p) 
         }
     };
 
+    STAMP(0);
     int g = 0;  // linear step; LDS weight buffer of step g is g & 1, its registers rwa (even) / rwb (odd)
     for (int cc = 0; cc < p.nchunks; ++cc) {
         // ---- stage the halo patch of this channel chunk (prologue applied once per element)
@@ -222,12 +239,15 @@ __global__ __launch_bounds__(256) void conv3x3_halo1_kernel(const HaloParams p) 
         }
         if (cc == 0) halo1_store_w(rwa, wl, w_row0, w_chunk);   // step 0 -> buffer 0 (later chunks: done in the tap loop)
         __syncthreads();
+        if (cc == 0) STAMP(1);
         // ---- nine taps (parity of the first step alternates between chunks: two instantiations)
         if ((g & 1) == 0) run_chunk(std::integral_constant<int, 0>{}, g);
         else run_chunk(std::integral_constant<int, 1>{}, g);
         g += 9;
         __syncthreads();   // every wave is done with this chunk's halo image before it is restaged
+        if (cc == 0) STAMP(2);
     }
+    STAMP(3);
 
     conv_epilogue<T>(smem, acc, a, n0, p.PQ,
                      [&](int row) {
@@ -236,6 +256,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo1_kernel(const HaloParams p) 
                          return img < a.N ? (img * H + oy0 + ty) * W + ox0 + tx : -1;
                      },
                      tile_m * 4 + wid);
+    STAMP(4);
 }
 
 // ===== variant 2: TPS taps per weight stage, HB halo images (deep pipeline for small-M tiles) =====
@@ -319,6 +340,16 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const HaloParam
         halo_load_w<TPS, T::B_ITERS>(rw, w_ptr, a.kpad, C, st * TPS, cc);
     };
 
+    // ---- halo decode (ti, hy, hx) of the chunks this thread stages: identical for every channel chunk,
+    // so the two runtime integer divisions per chunk are paid once
+    int hdec[HIT];
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+        const int hp = (tid + 256 * it) >> 3;
+        const int hx = hp % p.HW, tt = hp / p.HW;
+        hdec[it] = hx | ((tt % p.HH) << 8) | ((tt / p.HH) << 16);
+    }
+
     // ---- halo patch of one channel chunk: issue (global -> registers) ... commit (prologue -> LDS)
     u32x4_t rh[HIT];
     int gofs[HIT];
@@ -332,9 +363,8 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const HaloParam
             u32x4_t v = {0u, 0u, 0u, 0u};
             gofs[it] = -1;
             if (idx < total) {
-                const int hp = idx >> 3, ch = idx & 7;
-                const int hx = hp % p.HW, t = hp / p.HW;
-                const int hy = t % p.HH, ti = t / p.HH;
+                const int ch = idx & 7;
+                const int hx = hdec[it] & 255, hy = (hdec[it] >> 8) & 255, ti = hdec[it] >> 16;
                 const int img = img0 + ti, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
                 if (img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
                     v = *reinterpret_cast<const u32x4_t *>(src + ((size_t)(img * H + iy) * W + ix) * C + cc * 64 + ch * 8);
@@ -470,20 +500,24 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const HaloParam
     };
 
     // ---- prologue: chunk 0 halo + stages 0 (-> LDS) and 1, 2 (-> registers)
+    STAMP(0);
     halo_issue(0);
     load_stage(rwa, 0);
     if (nstages > 1) load_stage(rwb, 1);
     halo_commit(halo);
     halo_store_w<TPS, T::B_ITERS, BN>(rwa, wl, w_row0, w_chunk);
     __syncthreads();
+    STAMP(1);
     if (HB == 2 && p.nchunks > 1) halo_issue(1);
     if (nstages > 2) load_stage(rwa, 2);
     read_frags(fp0, fw0, 0, 0, 0, 0);
     for (int cc = 0; cc < p.nchunks; ++cc) {
         if ((cc & 1) == 0) run_chunk(std::integral_constant<int, 0>{}, cc);
         else run_chunk(std::integral_constant<int, 1>{}, cc);
+        if (cc == 0) STAMP(2);
     }
     __syncthreads();   // every wave is done with the LDS images before the epilogue overlays them
+    STAMP(3);
 
     conv_epilogue<T>(smem, acc, a, n0, p.PQ,
                      [&](int row) {
@@ -492,6 +526,7 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_halo_kernel(const HaloParam
                          return img < a.N ? (img * H + oy0 + ty) * W + ox0 + tx : -1;
                      },
                      tile_m * 4 + wid);
+    STAMP(4);
 }
 
 bool geometry(const combat_conv_args *a, int BM, int BN, HaloParams &p, int &smem, int TPS = 1, int HB = 1) {
@@ -519,9 +554,9 @@ bool geometry(const combat_conv_args *a, int BM, int BN, HaloParams &p, int &sme
     return smem <= 150 * 1024;
 }
 
-template <int BM, int BN, int WGM>
+template <int BM, int BN, int WGM, int MINW>
 int launch_halo1(const HaloParams &p, int smem, hipStream_t st) {
-    auto kern = conv3x3_halo1_kernel<BM, BN, WGM>;
+    auto kern = conv3x3_halo1_kernel<BM, BN, WGM, MINW>;
     static int attr_bytes = 0;
     if (smem > attr_bytes) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -564,6 +599,8 @@ bool applicable(const combat_conv_args *a) {
 
 // tile id (COMBAT_TILE_H*) the halo kernel would use for these args, or 0 if it does not apply
 int conv3x3_pick(const combat_conv_args *a) {
+    if (const int d = conv3x3d_pick(a)) return d;
+    if (a->tile >= COMBAT_TILE_D128x64) return 0;
     if (!applicable(a)) return 0;
     if (a->tile) {
         for (const Cand &c : kCands)
@@ -587,6 +624,7 @@ int conv3x3_pick(const combat_conv_args *a) {
 }
 
 int conv3x3_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {
+    if (tile >= COMBAT_TILE_D128x64) return conv3x3d_stats_layout(a, tile, rows, rows_per_image);
     for (const Cand &c : kCands)
         if (c.tile == tile) {
             HaloParams p;
@@ -601,19 +639,20 @@ int conv3x3_stats_layout(const combat_conv_args *a, int tile, int *rows, int *ro
 }
 
 int conv3x3_launch(const combat_conv_args *a, int tile, hipStream_t st) {
+    if (tile >= COMBAT_TILE_D128x64) return conv3x3d_launch(a, tile, st);
     HaloParams p;
     int smem;
     switch (tile) {
         case COMBAT_TILE_H256x64:
             if (!geometry(a, 256, 64, p, smem)) return COMBAT_EINVAL;
-            return launch_halo1<256, 64, 4>(p, smem, st);
+            return launch_halo1<256, 64, 4, 1>(p, smem, st);
         case COMBAT_TILE_H128x128:
             if (!geometry(a, 128, 128, p, smem)) return COMBAT_EINVAL;
-            return launch_halo1<128, 128, 2>(p, smem, st);
+            return launch_halo1<128, 128, 2, 1>(p, smem, st);
         case COMBAT_TILE_H128x64:
             // large-M layers: small LDS footprint, several workgroups per CU overlap each other's phases
             if (!geometry(a, 128, 64, p, smem)) return COMBAT_EINVAL;
-            return launch_halo1<128, 64, 2>(p, smem, st);
+            return launch_halo1<128, 64, 2, 1>(p, smem, st);
         case COMBAT_TILE_H64x64:
             // small-M layers (one workgroup per CU, many channel chunks): weights staged three taps at a
             // time and the next chunk's halo patch prefetched into a second LDS image

@@ -1,0 +1,539 @@
+// 3x3 / stride-1 / pad-1 convolution (forward and input-gradient) WITHOUT an input prologue, with both
+// operands moved global -> LDS by the DMA path (buffer_load ... lds, 16 bytes per lane).
+//
+// The halo kernels of conv3x3.hip stage their operands through registers because the BatchNorm /
+// InstanceNorm prologue has to touch every input element.  Convolutions whose input is already in
+// its final form (every input-gradient pass; forwards whose producer applied the activation) need no
+// VALU work on the way in, so here no operand byte ever visits a VGPR before its MFMA fragment read:
+//   * per 64-channel chunk the (TH+2) x (TW+2) halo patch of the workgroup's 128 pixels is DMA'd
+//     once; out-of-image pixels use an out-of-range buffer offset, which the hardware returns -- and
+//     writes to LDS -- as zeros (the padding);
+//   * per (chunk, tap) step the BN x 64 weight tile is DMA'd into a three-deep ring, two steps ahead
+//     of its use; the only synchronisation per step is one counted s_waitcnt vmcnt + one s_barrier.
+// An LDS-DMA instruction writes 64 lanes x 16 B contiguously, so rows cannot be padded; instead the
+// eight 16-byte slots of every 128-byte row are ROTATED by (row & 6): slot = (chunk + (row & 6)) & 7,
+// applied on the global-address side.  For any 16 consecutive rows this makes ds_read_b128 fragment
+// reads bank-conflict-free (the same property the 160-byte row pitch gives the halo kernels).  The
+// halo row pitch is a multiple of 8 pixels, so the rotation depends on the tap's column offset only
+// and every fragment read is "precomputed VGPR + immediate".
+//
+// The fused epilogue (bias, residuals, activation mask, normalisation statistics: the same semantics
+// as conv_common.hpp's) is wave-private: each wave transposes its 32 pixels x BN channels through LDS
+// and its operand fetches are issued four steps before the main loop ends.
+#include "conv_common.hpp"
+
+#ifdef COMBAT_STAMPS   // in-kernel phase stamps of profiling builds: the buffer pointer travels as a kernel argument
+static unsigned long long *g_stamps_dma_host = nullptr;
+extern "C" int combat_debug_set_stamps_dma(void *p) { g_stamps_dma_host = (unsigned long long *)p; return 0; }
+#define DSTAMP(k)                                                                                        \
+    do {                                                                                                 \
+        if (threadIdx.x == 0 && p.stamps) p.stamps[blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); \
+        if (threadIdx.x == 0 && p.stamps && ((k) == 0 || (k) == 4)) p.stamps[blockIdx.x * 16 + 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define DSTAMP(k)
+#endif
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr unsigned kOob = 0x40000000u;  // buffer offset beyond every tensor on this path: reads as zeros
+
+struct DmaParams {
+    combat_conv_args a;
+    int tiles_x, tiles_y, tiles_m, tiles_n;
+    int PQ, nchunks;
+    unsigned src_bytes, w_bytes;
+    unsigned long long *stamps;   // profiling builds only
+};
+
+// geometry class of a 128-pixel tile, keyed by the tile width
+template <int TW>
+struct DGeo {
+    static constexpr int TH = TW == 4 ? 4 : 8;
+    static constexpr int TI = 128 / (TW * TH);
+    static constexpr int HH = TH + 2;
+    // halo row pitch in pixels.  The slot rotation is keyed on the halo COLUMN (hx & 6), so a tap's row
+    // offset (a multiple of the pitch) never changes it; the 16 pixels of a fragment lie in one halo
+    // row (TW 16) or in rows whose equal columns fall into the same rotation class (TW 8), which keeps
+    // ds_read_b128 conflict-free for any pitch.  TW 4 keeps the power-of-two pitch.
+    static constexpr int HWP = TW == 4 ? 8 : TW + 2;
+    static constexpr int HROWS = TI * HH * HWP;     // LDS rows (pixels) of one halo image
+    static constexpr int HPW = (HROWS + 31) / 32;   // 1-KiB DMA pieces (8 rows) per wave
+    static constexpr int HBYTES = HPW * 4 * 1024;   // every wave issues the same number of pieces
+    static constexpr int TW_SHIFT = TW == 16 ? 4 : (TW == 8 ? 3 : 2);
+    static constexpr int TH_SHIFT = TH == 8 ? 3 : 2;
+};
+
+template <int VM>
+__device__ __forceinline__ void wait_vm_lgkm0() {   // counted DMA wait + all of this wave's LDS reads back
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(VM) : "memory");
+}
+
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// HB = halo images in LDS: 1 for single-chunk layers (C = 64), 2 otherwise (the next chunk's patch is
+// DMA'd while the current one is consumed)
+template <int BN, int TW, int HB>
+__device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
+    constexpr int BM = 128;
+    using T = TileCfg<BM, BN, 4>;   // four waves along the pixels: a wave owns 32 pixels x all BN channels
+    using G = DGeo<TW>;
+    constexpr int WPW = BN / 32;            // weight DMA pieces per wave and step
+    constexpr int WBYTES = BN * 128;        // one ring slot
+    constexpr int HBYTES = G::HBYTES;
+    constexpr int HPW = G::HPW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const combat_conv_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile_m, tile_n;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = swz % p.tiles_n;
+        tile_m = swz / p.tiles_n;
+    }
+    const int n0 = tile_n * BN;
+    const int tx_ = tile_m % p.tiles_x, ty_ = (tile_m / p.tiles_x) % p.tiles_y, ig = tile_m / (p.tiles_x * p.tiles_y);
+    const int img0 = ig * G::TI, oy0 = ty_ * G::TH, ox0 = tx_ * TW;
+    const int C = a.C, H = a.H, W = a.W;
+    unsigned char *halo = smem;
+    unsigned char *wring = smem + HB * HBYTES;
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
+
+    // ---- per-lane DMA source offsets (bytes): chunk / tap terms are added through the scalar offset
+    unsigned hvoff[HPW];
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        const int row = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
+        const int hx = row % G::HWP, t = row / G::HWP;
+        const int hy = t % G::HH, ti = t / G::HH;
+        const int chunk = (slot - (hx & 6)) & 7;
+        const int img = img0 + ti, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+        const bool ok = row < G::HROWS && hx < TW + 2 && img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        hvoff[j] = ok ? (unsigned)((((img * H + iy) * W + ix) * C + chunk * 8) * 2) : kOob;
+    }
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int n = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
+        const int chunk = (slot - (n & 6)) & 7;
+        wvoff[j] = (unsigned)(((n0 + n) * a.kpad + chunk * 8) * 2);
+    }
+    auto issue_h = [&](int cc, int hbuf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < HPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(halo + hbuf * HBYTES + (wid + 4 * j) * 1024), 16,
+                                                     hvoff[j], cc * 128, 0, 0);
+    };
+    // weights of loop position t of chunk cc (dgrad walks the filter taps mirrored: tap 8 - t)
+    auto issue_w = [&](int t, int cc, int slot) __attribute__((always_inline)) {
+        const int tap = a.mode == 0 ? t : 8 - t;
+        const int soff = (tap * C + cc * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(wring + slot * WBYTES + (wid + 4 * j) * 1024), 16,
+                                                     wvoff[j], soff, 0, 0);
+    };
+
+    // ---- per-lane fragment read offsets: pixel fragment j at column offset dx, k-step ks
+    int pa[2][T::FM][3];
+#pragma unroll
+    for (int j = 0; j < T::FM; ++j) {
+        const int pj = wid * 32 + j * 16 + (lane & 15);
+        const int tx = pj & (TW - 1), ty = (pj >> G::TW_SHIFT) & (G::TH - 1), ti = pj >> (G::TW_SHIFT + G::TH_SHIFT);
+        const int r0 = (ti * G::HH + ty) * G::HWP + tx;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int s0 = ((lane >> 4) + ((tx + dx) & 6)) & 7;
+            pa[0][j][dx] = (r0 + dx) * 128 + s0 * 16;
+            pa[1][j][dx] = (r0 + dx) * 128 + (s0 ^ 4) * 16;
+        }
+    }
+    int wa[2];
+    {
+        const int n = lane & 15;
+        const int s0 = ((lane >> 4) + (n & 6)) & 7;
+        wa[0] = n * 128 + s0 * 16;
+        wa[1] = n * 128 + (s0 ^ 4) * 16;
+    }
+
+    f32x4_t acc[T::FN][T::FM];
+#pragma unroll
+    for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragments of one k-step (32 channels) of loop position t: FM pixel + FN weight reads
+    auto read_frags = [&](bf16x8_t (&fp)[T::FM], bf16x8_t (&fw)[T::FN], auto t_tag, auto ks_tag, auto hbuf_tag) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_tag)::value, ks = decltype(ks_tag)::value, hbuf = decltype(hbuf_tag)::value;
+        constexpr int dy = t / 3, dx = t % 3;
+        const unsigned char *hb = halo + hbuf * HBYTES + dy * G::HWP * 128;
+        const unsigned char *wb = wring + (t % 3) * WBYTES;
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j) fp[j] = *reinterpret_cast<const bf16x8_t *>(hb + pa[ks][j][dx]);
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i) fw[i] = *reinterpret_cast<const bf16x8_t *>(wb + wa[ks] + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_frags = [&](const bf16x8_t (&fp)[T::FM], const bf16x8_t (&fw)[T::FN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fp[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- fused epilogue.  A wave owns 32 pixels x BN channels; it transposes its accumulators through a
+    // private LDS image (no workgroup barrier) so that every global access is 16 bytes of 8 consecutive
+    // channels and 8 lanes cover one pixel's 128 contiguous bytes.  Residual / mask operands and the
+    // per-channel tables come through buffer loads (rows beyond the last image and absent tensors use
+    // an out-of-range offset / empty resource: loads give zeros, stores are dropped); they are issued
+    // in the middle of the main loop's last chunk, so that their latency is covered by the remaining
+    // MFMA steps -- the counted waits of those steps include them.
+    const int fr = lane & 15, fq = lane >> 4;
+    const int K = a.K;
+    const unsigned dst_bytes = (unsigned)(a.N * p.PQ) * (unsigned)K * 2u;
+    const __amdgpu_buffer_rsrc_t r_pre = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_pre), 0, a.add_pre ? dst_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.mask_x), 0, a.mask_x ? dst_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_post = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_post), 0, a.add_post ? dst_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, dst_bytes, 0x00020000);
+    constexpr int NC = T::NC;                // 16-byte chunks per dst row of the tile
+    constexpr int EQ = 32 * NC / 64;         // (row, chunk) items per lane
+    const int ec = lane % NC;                // this lane's chunk: channels n0 + 8 ec .. + 7
+    unsigned evoff[EQ];
+    bool ragged = false;                     // does this wave touch rows beyond the last image?
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) {
+        const int row = wid * 32 + (q * 64 + lane) / NC;
+        const int tx = row & (TW - 1), ty = (row >> G::TW_SHIFT) & (G::TH - 1);
+        const int img = img0 + (row >> (G::TW_SHIFT + G::TH_SHIFT));
+        evoff[q] = img < a.N ? (unsigned)((((img * H + oy0 + ty) * W + ox0 + tx) * K + n0 + ec * 8) * 2) : kOob;
+    }
+    if (G::TI > 1) ragged = img0 + G::TI > a.N;
+    // per-channel tables of this lane's 8 channels (empty resource = absent table = zeros)
+    const unsigned tab_bytes = (unsigned)K * 4u;
+    const bool kind2 = a.stats_kind == 2;
+    const __amdgpu_buffer_rsrc_t r_msc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mask_scale), 0, a.mask_scale ? tab_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_msh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mask_shift), 0, a.mask_scale ? tab_bytes : 0u, 0x00020000);
+    constexpr int NPF = 3 * EQ + 4;   // operand + mask-table fetches in flight
+    u32x4_t e_pre[EQ], e_x[EQ], e_post[EQ];
+    f32x4_t t_msc[2], t_msh[2];
+    auto epilogue_fetch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) {
+            e_pre[q] = __builtin_amdgcn_raw_buffer_load_b128(r_pre, evoff[q], 0, 0);
+            e_x[q] = __builtin_amdgcn_raw_buffer_load_b128(r_x, evoff[q], 0, 0);
+            e_post[q] = __builtin_amdgcn_raw_buffer_load_b128(r_post, evoff[q], 0, 0);
+        }
+        const int tb = (n0 + ec * 8) * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            t_msc[h] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_msc, tb + 16 * h, 0, 0));
+            t_msh[h] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_msh, tb + 16 * h, 0, 0));
+        }
+    };
+
+    // ---- main loop, software pipelined.  Loop position t of a chunk = filter tap; its weights live in
+    // ring slot t % 3 and are DMA'd three positions ahead.  A position is two k-steps; its fragments
+    // are read one k-step ahead into the other register set:
+    //     read(t, k1) -> B | MFMA(A)  [t, k0] | wait W(t+1), barrier, DMA W(t+3) | read(t+1, k0) -> A | MFMA(B)  [t, k1]
+    // so every LDS read has an MFMA block to land behind, and the one barrier per position sits between
+    // two MFMA blocks.  At the barrier every wave has all its reads of slot t % 3 back (lgkmcnt(0)), so the
+    // DMA of position t + 3 may overwrite it.  Counted vmcnt: what may stay in flight at the wait of
+    // position t is everything issued after W(t+1): W(t+2) and, if issued one or two positions ago,
+    // the next chunk's halo patch (issued at t = 0) / the epilogue operands (issued at t = PF_T).
+    constexpr int PF_T = 4;
+    const int nchunks = p.nchunks;
+    bf16x8_t fpA[T::FM], fwA[T::FN], fpB[T::FM], fwB[T::FN];
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    DSTAMP(0);
+#ifdef COMBAT_STAMPS
+    if (threadIdx.x == 0 && p.stamps) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.stamps[blockIdx.x * 16 + 15] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+    issue_h(0, 0);
+    issue_w(0, 0, 0);
+    issue_w(1, 0, 1);
+    issue_w(2, 0, 2);
+    wait_vm_lgkm0<2 * WPW>();
+    block_barrier();
+    DSTAMP(1);
+    read_frags(fpA, fwA, I0{}, I0{}, I0{});
+
+    auto chunk = [&](auto last_tag, auto hbuf_tag, int cc) __attribute__((always_inline)) {
+        constexpr bool last = decltype(last_tag)::value;
+        constexpr int hbuf = decltype(hbuf_tag)::value;
+        using HBUF = std::integral_constant<int, hbuf>;
+        using HNEXT = std::integral_constant<int, HB == 2 ? (hbuf ^ 1) : 0>;
+#define COMBAT_DMA_POS(t)                                                                                    \
+    {                                                                                                        \
+        using TT = std::integral_constant<int, t>;                                                           \
+        using TN = std::integral_constant<int, (t + 1) % 9>;                                                 \
+        read_frags(fpB, fwB, TT{}, I1{}, HBUF{});                                                            \
+        mfma_frags(fpA, fwA);                                                                                \
+        if (!(last && t == 8)) {                                                                             \
+            constexpr int n_w = (last && t >= 7) ? 0 : WPW;                                                  \
+            constexpr int n_h = (!last && (t == 1 || t == 2)) ? HPW : 0;                                     \
+            constexpr int n_e = (last && (t == PF_T + 1 || t == PF_T + 2)) ? NPF : 0;                        \
+            wait_vm_lgkm0<n_w + n_h + n_e>();                                                                \
+            block_barrier();                                                                                 \
+            if (t + 3 < 9) issue_w(t + 3, cc, t % 3);                                                        \
+            else if (!last) issue_w(t + 3 - 9, cc + 1, t % 3);                                               \
+            if (t == 0 && !last) issue_h(cc + 1, HNEXT::value);                                              \
+            if (last && t == PF_T) epilogue_fetch();                                                         \
+            if (t < 8) read_frags(fpA, fwA, TN{}, I0{}, HBUF{});                                             \
+            else read_frags(fpA, fwA, TN{}, I0{}, HNEXT{});                                                  \
+        }                                                                                                    \
+        mfma_frags(fpB, fwB);                                                                                \
+    }
+        COMBAT_DMA_POS(0) COMBAT_DMA_POS(1) COMBAT_DMA_POS(2) COMBAT_DMA_POS(3) COMBAT_DMA_POS(4)
+        COMBAT_DMA_POS(5) COMBAT_DMA_POS(6) COMBAT_DMA_POS(7) COMBAT_DMA_POS(8)
+#undef COMBAT_DMA_POS
+        if (cc == 0) DSTAMP(2);
+    };
+    if (HB == 1) {
+        chunk(std::true_type{}, I0{}, 0);
+    } else {
+        int cc = 0;
+        for (; cc + 2 < nchunks; cc += 2) {
+            chunk(std::false_type{}, I0{}, cc);
+            chunk(std::false_type{}, I1{}, cc + 1);
+        }
+        if (cc + 2 == nchunks) {
+            chunk(std::false_type{}, I0{}, cc);
+            chunk(std::true_type{}, I1{}, cc + 1);
+        } else {
+            chunk(std::true_type{}, I0{}, cc);
+        }
+    }
+    DSTAMP(3);
+
+    // ---- epilogue: accumulators -> this wave's fp32 LDS image (the operand images are dead once every
+    // wave has passed the barrier) -> row-major items
+    block_barrier();
+    float *ep = reinterpret_cast<float *>(smem) + wid * (32 * T::EPS);
+#pragma unroll
+    for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j)
+            *reinterpret_cast<f32x4_t *>(ep + (j * 16 + fr) * T::EPS + i * 16 + fq * 4) = acc[i][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS accesses execute in order
+    DSTAMP(5);
+
+    const bool has_mask = a.mask_x != nullptr, has_scale = a.mask_scale != nullptr;
+    const bool mul_scale = a.mask_mul_scale != 0;
+    const int n = n0 + ec * 8;
+    float bias8[8], msc[8], msh[8], hrs[8], hmn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bias8[e] = hrs[e] = hmn[e] = 0.f;
+        msc[e] = has_scale ? t_msc[e >> 2][e & 3] : 1.f;   // without a table the mask is sign(x)
+        msh[e] = t_msh[e >> 2][e & 3];
+    }
+    if (a.bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
+    if (kind2) {
+        load8f(a.xh_rstd + n, hrs);
+        load8f(a.xh_mean + n, hmn);
+    }
+    float mfac[8];   // factor of a kept element: the scale (BatchNorm backward) or 1
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mfac[e] = mul_scale ? msc[e] : 1.f;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    u32x4_t packed[EQ];
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) {
+        const int r = (q * 64 + lane) / NC;
+        float v[8], t[8], xm[8];
+        load8f(ep + r * T::EPS + ec * 8, v);
+        unpack8v(e_pre[q], t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias8[e] + t[e];
+        if (has_mask) {
+            unpack8v(e_x[q], xm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)   // msc = 1, msh = 0 without a table
+                v[e] *= fmaf(xm[e], msc[e], msh[e]) > 0.f ? mfac[e] : mfac[e] * a.mask_slope;
+        }
+        unpack8v(e_post[q], t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += t[e];
+        packed[q] = pack8v(v);
+        if (a.stats_kind) {
+            float vr[8];
+            unpack8v(packed[q], vr);
+            if (ragged && evoff[q] == kOob) {   // rows beyond the last image count as zeros
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vr[e] = 0.f;
+            }
+            if (kind2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += vr[e];
+                    s2[e] = fmaf(vr[e], (xm[e] - hmn[e]) * hrs[e], s2[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += vr[e];
+                    s2[e] = fmaf(vr[e], vr[e], s2[e]);
+                }
+            }
+        }
+    }
+    DSTAMP(6);
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed[q], r_dst, evoff[q], 0, 0);
+    DSTAMP(7);
+    if (a.stats_kind) {
+        // one statistics row per wave (32 pixels).  Lanes with equal chunk differ by multiples of NC:
+        // one pass through the wave's LDS image ([lane][16] partial sums; lane -> (chunk, value pair))
+        // instead of log2(64 / NC) dependent cross-lane shuffles of 16 values each.
+        float *sp = ep + lane * 20;   // 16 values + pad: 80-byte pitch keeps the 16-byte stores conflict-free
+        *reinterpret_cast<f32x4_t *>(sp) = f32x4_t{s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4_t *>(sp + 4) = f32x4_t{s1[4], s1[5], s1[6], s1[7]};
+        *reinterpret_cast<f32x4_t *>(sp + 8) = f32x4_t{s2[0], s2[1], s2[2], s2[3]};
+        *reinterpret_cast<f32x4_t *>(sp + 12) = f32x4_t{s2[4], s2[5], s2[6], s2[7]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // NC chunks x 16 values = NC * 16 sums; lane handles chunk (lane % NC), values vg .. vg + VPL - 1
+        constexpr int VPL = NC * 16 / 64;            // values per lane (2 or 4)
+        const int vg = (lane / NC) * VPL;
+        float tot[VPL];
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) tot[u] = 0.f;
+#pragma unroll
+        for (int src = 0; src < 64 / NC; ++src) {
+            const float *rp = ep + (src * NC + ec) * 20 + vg;
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) tot[u] += rp[u];
+        }
+        // value index v: 0..7 -> sum, 8..15 -> second moment, of channel n + (v & 7)
+        float *orow = a.stats + ((size_t)(tile_m * 4 + wid) * 2 + (vg >> 3)) * K + n + (vg & 7);
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) orow[u] = tot[u];
+    }
+    DSTAMP(4);
+}
+
+// (the body is a device function: the host pass cannot see the buffer-resource type it uses)
+template <int BN, int TW, int HB>
+__global__ __launch_bounds__(256, HB == 1 ? 3 : 2) void conv3x3_dma_kernel(const DmaParams p) {
+    conv3x3_dma_body<BN, TW, HB>(p);
+}
+
+int geo_tw(const combat_conv_args *a) {
+    if (a->W >= 16) return (a->W % 16 == 0 && a->H % 8 == 0) ? 16 : 0;
+    if (a->W == 8) return a->H == 8 ? 8 : 0;
+    if (a->W == 4) return a->H == 4 ? 4 : 0;
+    return 0;
+}
+
+bool applicable(const combat_conv_args *a, int BN) {
+    if (!(a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->P == a->H && a->Q == a->W)) return false;
+    if (a->pro_scale || a->pro_act) return false;   // operands go straight to LDS: no prologue
+    // epilogue: per-channel (BatchNorm) tables only -- per-image (InstanceNorm) tables and tanh stay
+    // with the halo kernels
+    if (a->tanh_out || (a->mask_x && a->mask_group_stride != 0)) return false;
+    if (a->C < 64 || (a->C & 63) || a->K % BN || a->kpad < 9 * a->C) return false;
+    if ((long)a->N * a->H * a->W * a->C * 2 >= (long)kOob) return false;
+    if ((long)a->rows_pad * a->kpad * 2 >= (long)kOob) return false;
+    if ((long)a->N * a->H * a->W * a->K * 2 >= (long)kOob) return false;
+    return geo_tw(a) != 0;
+}
+
+template <int TW>
+void fill(const combat_conv_args *a, int BN, DmaParams &p) {
+    using G = DGeo<TW>;
+    p.a = *a;
+    p.tiles_x = a->W / TW;
+    p.tiles_y = a->H / G::TH;
+    p.tiles_m = p.tiles_x * p.tiles_y * ((a->N + G::TI - 1) / G::TI);
+    p.tiles_n = a->K / BN;
+    p.PQ = a->H * a->W;
+    p.nchunks = a->C / 64;
+    p.src_bytes = (unsigned)((long)a->N * a->H * a->W * a->C * 2);
+    p.w_bytes = (unsigned)((long)a->rows_pad * a->kpad * 2);
+#ifdef COMBAT_STAMPS
+    p.stamps = g_stamps_dma_host;
+#else
+    p.stamps = nullptr;
+#endif
+}
+
+template <int BN, int TW, int HB>
+int launch_hb(const DmaParams &p, hipStream_t st) {
+    using G = DGeo<TW>;
+    constexpr int stage = HB * G::HBYTES + 3 * BN * 128;
+    constexpr int ep = 128 * (BN + 4) * 4;
+    constexpr int smem = stage > ep ? stage : ep;
+    auto kern = conv3x3_dma_kernel<BN, TW, HB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+template <int BN, int TW>
+int launch(const combat_conv_args *a, hipStream_t st) {
+    DmaParams p;
+    fill<TW>(a, BN, p);
+    return p.nchunks == 1 ? launch_hb<BN, TW, 1>(p, st) : launch_hb<BN, TW, 2>(p, st);
+}
+
+int tile_bn(int tile) { return tile == COMBAT_TILE_D128x64 ? 64 : 0; }
+
+}  // namespace
+
+// tile id the DMA kernel would use for these args (an explicit a->tile is honoured), or 0.
+// Measured on MI355X (profiles/r01_c_dma_tile_sweep.txt): wherever it applies it beats the
+// register-staged halo tiles (1.3-1.9x on the PreActResNet18 layer shapes).
+int conv3x3d_pick(const combat_conv_args *a) {
+    if (a->tile) {
+        const int bn = tile_bn(a->tile);
+        return bn && applicable(a, bn) ? a->tile : 0;
+    }
+    return applicable(a, 64) ? COMBAT_TILE_D128x64 : 0;
+}
+
+int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {
+    const int bn = tile_bn(tile);
+    if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
+    const int tw = geo_tw(a);
+    const int th = tw == 4 ? 4 : 8, ti = 128 / (tw * th);
+    const int tiles_m = (a->W / tw) * (a->H / th) * ((a->N + ti - 1) / ti);
+    *rows = tiles_m * 4;   // one row per wave = 32 pixels
+    *rows_per_image = ((tw * th) % 32 == 0) ? (a->H * a->W) / 32 : 0;
+    return COMBAT_OK;
+}
+
+int conv3x3d_launch(const combat_conv_args *a, int tile, hipStream_t st) {
+    const int bn = tile_bn(tile);
+    if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
+    const int tw = geo_tw(a);
+    if (tw == 16) return launch<64, 16>(a, st);
+    if (tw == 8) return launch<64, 8>(a, st);
+    return launch<64, 4>(a, st);
+}

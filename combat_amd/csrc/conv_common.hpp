@@ -7,6 +7,12 @@
 int conv3x3_pick(const combat_conv_args *a);
 int conv3x3_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image);
 int conv3x3_launch(const combat_conv_args *a, int tile, hipStream_t st);
+// DMA-staged variant for prologue-free convolutions (conv3x3_dma.hip), reached through the three above
+int conv3x3d_pick(const combat_conv_args *a);
+int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image);
+int conv3x3d_launch(const combat_conv_args *a, int tile, hipStream_t st);
+// halo weight-gradient kernel (conv_wgrad3x3.hip): 0 launched, 1 not applicable, <0 error
+int conv_wgrad3x3_try(const combat_wgrad_args *a, hipStream_t st);
 
 template <int BM, int BN, int WGM_ = 0>
 struct TileCfg {

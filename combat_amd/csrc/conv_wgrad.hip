@@ -13,7 +13,7 @@
 // Replaces the weight-gradient half of autograd's conv backward for the lines listed in
 // conv_gemm.hip; the prologue recomputes the normalised/activated conv input from the saved
 // pre-normalisation tensor, as the forward kernel does.
-#include "common.hpp"
+#include "conv_common.hpp"
 
 namespace {
 
@@ -282,6 +282,11 @@ extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
     p.M = (int)M;
     p.ntaps = a->R * a->S;
     hipStream_t st = as_stream(stream);
+    if (a->split >= 0) {   // split < 0 forces the generic kernel (tests)
+        const int rc = conv_wgrad3x3_try(a, st);
+        if (rc <= 0) return rc;
+    }
+    if (a->split < 0) p.a.split = 0;
     if (a->C <= 16) return launch<64, 16>(p, st);
     if (a->K <= 16) return launch<16, 64>(p, st);
     if (a->C % 128 == 0 && a->K % 128 == 0) return launch<128, 128>(p, st);

@@ -104,6 +104,10 @@ typedef struct combat_conv_args {
 #define COMBAT_TILE_H128x128 7
 #define COMBAT_TILE_H128x64 8
 #define COMBAT_TILE_H64x64 9
+/* the same convolutions when they have NO input prologue, per-channel (not per-image) mask tables
+ * and no tanh: both operands go global -> LDS by DMA (buffer_load ... lds), 128 pixels x 64
+ * channels per workgroup (conv3x3_dma.hip) */
+#define COMBAT_TILE_D128x64 10
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);
 /* tile the launcher would pick for these args (a->tile honoured) and its stats granule */
@@ -134,7 +138,9 @@ typedef struct combat_wgrad_args {
     int32_t pro_group_stride;
     int32_t pro_act;
     float pro_slope;
-    int32_t split;               /* 0 = auto: number of pixel ranges */
+    int32_t split;               /* number of pixel ranges: 0 = auto, > 0 explicit, < 0 = auto with the
+                                    generic per-tap kernel forced (3x3/s1 layers otherwise use the
+                                    LDS-patch kernel that computes all nine taps per workgroup) */
 } combat_wgrad_args;
 
 int combat_conv_wgrad(const combat_wgrad_args *a, void *stream);

@@ -99,14 +99,53 @@ def test_conv3x3_halo_forward_and_dgrad(ops, n, hw, c, k, tile):
     assert rel_l2(nchw(dx), torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1)) < 4e-3
 
 
-@pytest.mark.parametrize("n,hw,c,groups_per_image", [(4, 32, 64, True), (3, 8, 128, True), (8, 4, 128, True)])
-def test_conv3x3_halo_instance_stats_layout(ops, n, hw, c, groups_per_image):
-    """Statistics rows of the halo kernel are image-aligned whenever one wave's rows stay inside
-    an image; the per-image sums must then match."""
+DMA_CASES = [
+    # n, hw, c, k, tile   (prologue-free 3x3 convolutions with both operands DMA'd into LDS)
+    (4, 32, 64, 64, 10), (2, 32, 128, 128, 10), (3, 16, 128, 128, 10), (5, 16, 64, 128, 10), (3, 16, 256, 64, 10),
+    (3, 8, 256, 256, 10), (5, 8, 128, 64, 10), (2, 8, 64, 64, 10),      # two images per tile, ragged N
+    (9, 4, 512, 512, 10), (8, 4, 128, 256, 10), (3, 4, 64, 64, 10),     # eight images per tile
+]
+
+
+@pytest.mark.parametrize("n,hw,c,k,tile", DMA_CASES)
+def test_conv3x3_dma_forward_and_dgrad(ops, n, hw, c, k, tile):
+    from combat_amd._lib import lib
+    import ctypes
+    x = torch.randn(n, c, hw, hw, generator=g(1))
+    w, pc = make_conv(ops, k, c, 3, 1, 1, 2)
+    y = torch.empty(n, hw, hw, k, dtype=bf16, device="cuda")
+    res = torch.randn(n, k, hw, hw, generator=g(6))
+    a = ops.conv_args(nhwc(x), y, pc, 0, add_post=nhwc(res), stats_kind=1, tile=tile)
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) == tile
+    rows, rpi = ops.conv_stats_layout(a)
+    stats = torch.zeros(rows, 2, k, device="cuda")
+    a.stats = stats.data_ptr()
+    ops.conv_launch(a)
+    ref = F.conv2d(rb(x), rb(w), padding=1) + rb(res)
+    assert rel_l2(nchw(y), ref) < 4e-3
+    yr = nchw(y)
+    assert rel_l2(stats.sum(0).cpu()[0], yr.sum((0, 2, 3))) < 1e-4
+    if rpi:
+        per_img = stats[: n * rpi].view(n, rpi, 2, k).sum(1).cpu()
+        assert rel_l2(per_img[:, 1], (yr * yr).sum((2, 3))) < 1e-4
+    dy = torch.randn(n, k, hw, hw, generator=g(3))
+    dx = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(dy), dx, pc, 1, tile=tile)
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) == tile
+    ops.conv_launch(a)
+    assert rel_l2(nchw(dx), torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1)) < 4e-3
+
+
+@pytest.mark.parametrize("n,hw,c,groups_per_image,tile", [(4, 32, 64, True, 0), (3, 8, 128, True, 0), (8, 4, 128, True, 9),
+                                                        (8, 4, 128, False, 0)])
+def test_conv3x3_halo_instance_stats_layout(ops, n, hw, c, groups_per_image, tile):
+    """Statistics rows of the 3x3 kernels are image-aligned whenever one wave's rows stay inside an
+    image (4x4 images: only with the 64-pixel halo tile; the automatic 128-pixel DMA tile puts two
+    images into a wave's 32 rows); the per-image sums must then match."""
     x = torch.randn(n, c, hw, hw, generator=g(4))
     w, pc = make_conv(ops, c, c, 3, 1, 1, 5)
     y = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
-    a = ops.conv_args(nhwc(x), y, pc, 0, stats_kind=1)
+    a = ops.conv_args(nhwc(x), y, pc, 0, stats_kind=1, tile=tile)
     rows, rpi = ops.conv_stats_layout(a)
     assert (rpi > 0) == groups_per_image
     stats = torch.zeros(rows, 2, c, device="cuda")
@@ -275,6 +314,35 @@ def test_wgrad_with_prologue(ops):
     dw = torch.zeros(k, 9, c, device="cuda")
     ops.conv_wgrad(nhwc(x), nhwc(dy), pc, dw, pro=ops.Affine(dev(sc), dev(sh), c, True, 0.2))
     assert rel_l2(dw, ref.permute(0, 2, 3, 1).reshape(k, 9, c)) < 2e-3
+
+
+@pytest.mark.parametrize("n,hw,c,k,per_image", [
+    (4, 32, 64, 64, False), (3, 16, 128, 64, True), (5, 8, 64, 128, True), (6, 4, 128, 128, False),
+    (9, 4, 64, 64, True), (7, 2, 128, 64, True), (33, 2, 64, 64, False)])
+def test_wgrad3x3_halo_kernel(ops, n, hw, c, k, per_image):
+    """3x3/s1 weight gradient with the input patch in LDS and all nine taps per workgroup: BatchNorm
+    (per-channel) and InstanceNorm (per-image) prologues, several images per 64-pixel tile, ragged N;
+    also against the generic kernel (split < 0 forces it)."""
+    x = torch.randn(n, c, hw, hw, generator=g(45))
+    shape = (n, c) if per_image else (c,)
+    sc, sh = torch.rand(shape, generator=g(46)) + 0.5, torch.randn(shape, generator=g(47)) * 0.3
+    w, pc = make_conv(ops, k, c, 3, 1, 1, 48)
+    dy = torch.randn(n, k, hw, hw, generator=g(49))
+    bsc = sc[:, :, None, None] if per_image else sc[None, :, None, None]
+    bsh = sh[:, :, None, None] if per_image else sh[None, :, None, None]
+    act = rb(F.leaky_relu(rb(x) * bsc + bsh, 0.2))
+    ref = torch.nn.grad.conv2d_weight(act, (k, c, 3, 3), rb(dy), padding=1).permute(0, 2, 3, 1).reshape(k, 9, c)
+    pro = ops.Affine(dev(sc), dev(sh), c if per_image else 0, True, 0.2)
+    xd, dyd = nhwc(x), nhwc(dy)
+    dw = torch.zeros(k, 9, c, device="cuda")
+    ops.conv_wgrad(xd, dyd, pc, dw, pro=pro)
+    assert rel_l2(dw, ref) < 2e-3
+    dw2 = torch.zeros(k, 9, c, device="cuda")
+    ops.conv_wgrad(xd, dyd, pc, dw2, pro=pro, split=-1)
+    assert rel_l2(dw2, ref) < 2e-3
+    dw3 = torch.zeros(k, 9, c, device="cuda")
+    ops.conv_wgrad(xd, dyd, pc, dw3, pro=pro, split=3)      # explicit number of pixel ranges
+    assert rel_l2(dw3, ref) < 2e-3
 
 
 def test_pack_weights_layouts(ops):
