@@ -27,9 +27,10 @@ class ConvArgs(C.Structure):
         ("pro_scale", c_vp), ("pro_shift", c_vp), ("pro_group_stride", c_i32), ("pro_act", c_i32),
         ("pro_slope", c_f32),
         ("bias", c_vp), ("add_pre", c_vp), ("mask_x", c_vp), ("mask_scale", c_vp), ("mask_shift", c_vp),
-        ("mask_group_stride", c_i32), ("mask_slope", c_f32), ("mask_mul_scale", c_i32),
+        ("mask_activated", c_i32), ("mask_group_stride", c_i32), ("mask_slope", c_f32), ("mask_mul_scale", c_i32),
         ("add_post", c_vp), ("tanh_out", c_i32),
         ("stats_kind", c_i32), ("stats", c_vp), ("xh_mean", c_vp), ("xh_rstd", c_vp),
+        ("act_dst", c_vp), ("act_scale", c_vp), ("act_shift", c_vp), ("act_slope", c_f32),
         ("tile", c_i32),
     ]
 

@@ -208,7 +208,8 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     const __amdgpu_buffer_rsrc_t r_pre = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_pre), 0, a.add_pre ? dst_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.mask_x), 0, a.mask_x ? dst_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_post = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_post), 0, a.add_post ? dst_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst ? dst_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc(a.act_dst, 0, a.act_dst ? dst_bytes : 0u, 0x00020000);
     constexpr int NC = T::NC;                // 16-byte chunks per dst row of the tile
     constexpr int EQ = 32 * NC / 64;         // (row, chunk) items per lane
     const int ec = lane % NC;                // this lane's chunk: channels n0 + 8 ec .. + 7
@@ -225,8 +226,11 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     // per-channel tables of this lane's 8 channels (empty resource = absent table = zeros)
     const unsigned tab_bytes = (unsigned)K * 4u;
     const bool kind2 = a.stats_kind == 2;
-    const __amdgpu_buffer_rsrc_t r_msc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mask_scale), 0, a.mask_scale ? tab_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_msh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.mask_shift), 0, a.mask_scale ? tab_bytes : 0u, 0x00020000);
+    // one (scale, shift) table pair travels with the operand prefetch: the mask tables (input-gradient
+    // passes) or the activation-output tables (forward passes) -- a launch never has both (applicable())
+    const float *tab_sc = a.mask_x ? a.mask_scale : a.act_scale, *tab_sh = a.mask_x ? a.mask_shift : a.act_shift;
+    const __amdgpu_buffer_rsrc_t r_msc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab_sc), 0, tab_sc ? tab_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_msh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab_sh), 0, tab_sh ? tab_bytes : 0u, 0x00020000);
     constexpr int NPF = 3 * EQ + 4;   // operand + mask-table fetches in flight
     u32x4_t e_pre[EQ], e_x[EQ], e_post[EQ];
     f32x4_t t_msc[2], t_msh[2];
@@ -337,15 +341,18 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS accesses execute in order
     DSTAMP(5);
 
-    const bool has_mask = a.mask_x != nullptr, has_scale = a.mask_scale != nullptr;
+    const bool has_mask = a.mask_x != nullptr, has_scale = a.mask_scale != nullptr, has_act = a.act_dst != nullptr;
     const bool mul_scale = a.mask_mul_scale != 0;
+    const bool plain_test = !has_scale || a.mask_activated;   // kept-test on mask_x itself
     const int n = n0 + ec * 8;
-    float bias8[8], msc[8], msh[8], hrs[8], hmn[8];
+    float bias8[8], msc[8], msh[8], hrs[8], hmn[8], tsc[8], tsh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         bias8[e] = hrs[e] = hmn[e] = 0.f;
-        msc[e] = has_scale ? t_msc[e >> 2][e & 3] : 1.f;   // without a table the mask is sign(x)
-        msh[e] = t_msh[e >> 2][e & 3];
+        tsc[e] = t_msc[e >> 2][e & 3];   // mask tables or activation-output tables
+        tsh[e] = t_msh[e >> 2][e & 3];
+        msc[e] = plain_test ? 1.f : tsc[e];
+        msh[e] = plain_test ? 0.f : tsh[e];
     }
     if (a.bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
     if (kind2) {
@@ -354,11 +361,11 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     }
     float mfac[8];   // factor of a kept element: the scale (BatchNorm backward) or 1
 #pragma unroll
-    for (int e = 0; e < 8; ++e) mfac[e] = mul_scale ? msc[e] : 1.f;
+    for (int e = 0; e < 8; ++e) mfac[e] = mul_scale ? tsc[e] : 1.f;
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    u32x4_t packed[EQ];
+    u32x4_t packed[EQ], packed_act[EQ];
 #pragma unroll
     for (int q = 0; q < EQ; ++q) {
         const int r = (q * 64 + lane) / NC;
@@ -377,6 +384,16 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += t[e];
         packed[q] = pack8v(v);
+        if (has_act) {   // the next layer's (eval BatchNorm + ReLU) prologue, applied to the stored value
+            float y[8];
+            unpack8v(packed[q], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float qa = fmaf(y[e], tsc[e], tsh[e]);
+                y[e] = qa > 0.f ? qa : qa * a.act_slope;
+            }
+            packed_act[q] = pack8v(y);
+        }
         if (a.stats_kind) {
             float vr[8];
             unpack8v(packed[q], vr);
@@ -402,6 +419,10 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     DSTAMP(6);
 #pragma unroll
     for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed[q], r_dst, evoff[q], 0, 0);
+    if (has_act) {
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed_act[q], r_act, evoff[q], 0, 0);
+    }
     DSTAMP(7);
     if (a.stats_kind) {
         // one statistics row per wave (32 pixels).  Lanes with equal chunk differ by multiples of NC:
@@ -452,6 +473,7 @@ bool applicable(const combat_conv_args *a, int BN) {
     // epilogue: per-channel (BatchNorm) tables only -- per-image (InstanceNorm) tables and tanh stay
     // with the halo kernels
     if (a->tanh_out || (a->mask_x && a->mask_group_stride != 0)) return false;
+    if (a->mask_x && a->act_dst) return false;   // one table pair travels with the operand prefetch
     if (a->C < 64 || (a->C & 63) || a->K % BN || a->kpad < 9 * a->C) return false;
     if ((long)a->N * a->H * a->W * a->C * 2 >= (long)kOob) return false;
     if ((long)a->rows_pad * a->kpad * 2 >= (long)kOob) return false;

@@ -67,6 +67,12 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const f32x4_t
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
     __bf16 *__restrict__ dst = reinterpret_cast<__bf16 *>(a.dst);
+    __bf16 *__restrict__ act_dst = reinterpret_cast<__bf16 *>(a.act_dst);
+    float asc[8], ash[8];
+    if (act_dst && n_ok) {
+        load8f(a.act_scale + n, asc);
+        load8f(a.act_shift + n, ash);
+    }
 
     // Per-channel tables are loop invariant when they are not per-image (BatchNorm): hoist them;
     // two instantiations so that no register array is conditionally rewritten (scratch).
@@ -136,7 +142,7 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const f32x4_t
                 if (a.mask_scale) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float qv = fmaf(xm[e], msc[e], msh[e]);
+                        const float qv = a.mask_activated ? xm[e] : fmaf(xm[e], msc[e], msh[e]);
                         float d = qv > 0.f ? 1.f : a.mask_slope;
                         if (a.mask_mul_scale) d *= msc[e];
                         v[e] *= d;
@@ -157,7 +163,17 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const f32x4_t
                 for (int e = 0; e < 8; ++e) v[e] = tanhf(v[e]);
             }
             const uint4 packed = pack8(v);
-            *reinterpret_cast<uint4 *>(dst + off) = packed;
+            if (dst) *reinterpret_cast<uint4 *>(dst + off) = packed;
+            if (act_dst) {   // the next layer's (eval BatchNorm + ReLU) prologue, applied to the stored value
+                float t[8];
+                unpack8(packed, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float q = fmaf(t[e], asc[e], ash[e]);
+                    t[e] = q > 0.f ? q : q * a.act_slope;
+                }
+                *reinterpret_cast<uint4 *>(act_dst + off) = pack8(t);
+            }
             if (a.stats_kind) {
                 float vr[8];
                 unpack8(packed, vr);

@@ -288,7 +288,8 @@ extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows
 }
 
 extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
-    if (!a || !a->src || !a->wpack || !a->dst) return COMBAT_EINVAL;
+    if (!a || !a->src || !a->wpack || (!a->dst && !a->act_dst)) return COMBAT_EINVAL;
+    if (a->act_dst && (!a->act_scale || !a->act_shift)) return COMBAT_EINVAL;
     if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->P <= 0 || a->Q <= 0) return COMBAT_EINVAL;
     if (a->C < 8 || a->K < 8 || (a->K & 7)) return COMBAT_EINVAL;
     if (a->R != a->S || (a->R != 1 && a->R != 3)) return COMBAT_EINVAL;

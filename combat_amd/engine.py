@@ -418,7 +418,7 @@ class PreActEngine(NetEngine):
         return slot.buf("x", (slot.N, slot.hw, slot.hw, 8))
 
     FWD_SHARED = ("stem", "logits", "dlogits", "pooled", "targets", "targets2") + tuple(
-        "b%d.%s" % (b, s) for b in range(8) for s in ("y1", "out", "sc"))
+        "b%d.%s" % (b, s) for b in range(8) for s in ("y1", "out", "sc", "a1", "act")) + ("stem.act",)
 
     def forward_plan(self, slot: Slot, train: bool, loss_weight: float = 1.0, with_targets2: bool = False,
                      split_head: bool = False) -> Plan:
@@ -431,41 +431,10 @@ class PreActEngine(NetEngine):
         P = Plan("preact." + key)
         n, hw = slot.N, slot.hw
         x = self.input(slot)
-        cur = slot.buf("stem", (n, hw, hw, 64))
-        first = self.blocks[0].bn1
-        if train:
-            st = self._conv_norm(P, slot, first.prefix, x, cur, self.stem, groups=1, gamma=first.gamma,
-                                 beta=first.beta, running=(first.rm, first.rv, first.nbt))
-            aff = Affine(st.scale, st.shift, 0, True, 0.0)
+        if not train:
+            cur, chw = self._forward_eval_body(P, slot, x)
         else:
-            rec_conv(P, "stem", x, cur, self.stem, 0)
-            aff = first.eval_affine()
-        chw = hw
-        for b, blk in enumerate(self.blocks):
-            ohw = chw // blk.stride
-            if blk.sc is not None:
-                resid = slot.buf("b%d.sc" % b, (n, ohw, ohw, blk.planes))
-                rec_conv(P, "b%d.sc" % b, cur, resid, blk.sc, 0, pro=aff)
-            else:
-                resid = cur
-            y1 = slot.buf("b%d.y1" % b, (n, ohw, ohw, blk.planes))
-            out = slot.buf("b%d.out" % b, (n, ohw, ohw, blk.planes))
-            nxt = self.blocks[b + 1].bn1 if b + 1 < len(self.blocks) else None
-            if train:
-                st2 = self._conv_norm(P, slot, blk.bn2.prefix, cur, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
-                                      beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt), pro=aff)
-                aff2 = Affine(st2.scale, st2.shift, 0, True, 0.0)
-                if nxt is not None:
-                    st = self._conv_norm(P, slot, nxt.prefix, y1, out, blk.conv2, groups=1, gamma=nxt.gamma,
-                                         beta=nxt.beta, running=(nxt.rm, nxt.rv, nxt.nbt), pro=aff2, add_post=resid)
-                    aff = Affine(st.scale, st.shift, 0, True, 0.0)
-                else:
-                    rec_conv(P, "b%d.c2" % b, y1, out, blk.conv2, 0, pro=aff2, add_post=resid)
-            else:
-                rec_conv(P, "b%d.c1" % b, cur, y1, blk.conv1, 0, pro=aff)
-                rec_conv(P, "b%d.c2" % b, y1, out, blk.conv2, 0, pro=blk.bn2.eval_affine(), add_post=resid)
-                aff = nxt.eval_affine() if nxt is not None else None
-            cur, chw = out, ohw
+            cur, chw = self._forward_train_body(P, slot, x)
         h = self.head_bufs(slot)
         P.hold(h)
         if not split_head:
@@ -493,6 +462,73 @@ class PreActEngine(NetEngine):
         slot.plans[key] = P
         slot.feat_hw = chw
         return P
+
+    def _forward_train_body(self, P: Plan, slot: Slot, x):
+        """Train mode: BatchNorm uses batch statistics, produced by the epilogue of the convolution
+        that writes the normalised tensor and consumed as the prologue of the next one."""
+        n, hw = slot.N, slot.hw
+        cur = slot.buf("stem", (n, hw, hw, 64))
+        first = self.blocks[0].bn1
+        st = self._conv_norm(P, slot, first.prefix, x, cur, self.stem, groups=1, gamma=first.gamma,
+                             beta=first.beta, running=(first.rm, first.rv, first.nbt))
+        aff = Affine(st.scale, st.shift, 0, True, 0.0)
+        chw = hw
+        for b, blk in enumerate(self.blocks):
+            ohw = chw // blk.stride
+            if blk.sc is not None:
+                resid = slot.buf("b%d.sc" % b, (n, ohw, ohw, blk.planes))
+                rec_conv(P, "b%d.sc" % b, cur, resid, blk.sc, 0, pro=aff)
+            else:
+                resid = cur
+            y1 = slot.buf("b%d.y1" % b, (n, ohw, ohw, blk.planes))
+            out = slot.buf("b%d.out" % b, (n, ohw, ohw, blk.planes))
+            nxt = self.blocks[b + 1].bn1 if b + 1 < len(self.blocks) else None
+            st2 = self._conv_norm(P, slot, blk.bn2.prefix, cur, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
+                                  beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt), pro=aff)
+            aff2 = Affine(st2.scale, st2.shift, 0, True, 0.0)
+            if nxt is not None:
+                st = self._conv_norm(P, slot, nxt.prefix, y1, out, blk.conv2, groups=1, gamma=nxt.gamma,
+                                     beta=nxt.beta, running=(nxt.rm, nxt.rv, nxt.nbt), pro=aff2, add_post=resid)
+                aff = Affine(st.scale, st.shift, 0, True, 0.0)
+            else:
+                rec_conv(P, "b%d.c2" % b, y1, out, blk.conv2, 0, pro=aff2, add_post=resid)
+            cur, chw = out, ohw
+        return cur, chw
+
+    def _forward_eval_body(self, P: Plan, slot: Slot, x):
+        """Eval mode: every BatchNorm is a fixed per-channel affine known before its producer runs, so the
+        producing convolution writes relu(bn(.)) itself (second epilogue output) and no convolution
+        needs a prologue -- the 3x3 / stride-1 layers then run on the DMA-staged kernel.  Tensors:
+        'stem.act' / 'b%d.act' = relu(bn1_next(block output)), 'b%d.a1' = relu(bn2(conv1 output));
+        the raw block output ('stem' / 'b%d.out') is kept only where an identity shortcut or the head
+        reads it."""
+        n, hw = slot.N, slot.hw
+        blocks = self.blocks
+        raw = slot.buf("stem", (n, hw, hw, 64)) if blocks[0].sc is None else None
+        act = slot.buf("stem.act", (n, hw, hw, 64))
+        rec_conv(P, "stem", x, raw, self.stem, 0, act_dst=act, act=blocks[0].bn1.eval_affine())
+        chw = hw
+        for b, blk in enumerate(blocks):
+            ohw = chw // blk.stride
+            shape = (n, ohw, ohw, blk.planes)
+            if blk.sc is not None:
+                resid = slot.buf("b%d.sc" % b, shape)
+                rec_conv(P, "b%d.sc" % b, act, resid, blk.sc, 0)
+            else:
+                resid = raw
+            a1 = slot.buf("b%d.a1" % b, shape)
+            rec_conv(P, "b%d.c1" % b, act, None, blk.conv1, 0, act_dst=a1, act=blk.bn2.eval_affine())
+            nxt = blocks[b + 1] if b + 1 < len(blocks) else None
+            keep_raw = nxt is None or nxt.sc is None
+            out = slot.buf("b%d.out" % b, shape) if keep_raw else None
+            if nxt is not None:
+                nact = slot.buf("b%d.act" % b, shape)
+                rec_conv(P, "b%d.c2" % b, a1, out, blk.conv2, 0, add_post=resid, act_dst=nact, act=nxt.bn1.eval_affine())
+            else:
+                nact = None
+                rec_conv(P, "b%d.c2" % b, a1, out, blk.conv2, 0, add_post=resid)
+            raw, act, chw = out, nact, ohw
+        return raw, chw
 
     def _block_io(self, slot: Slot, b: int):
         xin = slot.bufs["stem"] if b == 0 else slot.bufs["b%d.out" % (b - 1)]
@@ -565,17 +601,20 @@ class PreActEngine(NetEngine):
               d_out.data_ptr(), None, None)
         for b in reversed(range(len(self.blocks))):
             blk = self.blocks[b]
-            xin, y1, _ = self._block_io(slot, b)
-            dy1 = slot.buf("g.b%d.dy1" % b, y1.shape)
-            rec_conv(P, "b%d.c2.dgrad" % b, d_out, dy1, blk.conv2, 1, mask_x=y1, mask=blk.bn2.eval_affine(),
-                     mask_mul_scale=True)
+            # activated tensors of the eval forward: the ReLU mask is (act > 0), the BatchNorm scale multiplies
+            xact = slot.bufs["stem.act"] if b == 0 else slot.bufs["b%d.act" % (b - 1)]
+            a1 = slot.bufs["b%d.a1" % b]
+            dy1 = slot.buf("g.b%d.dy1" % b, a1.shape)
+            rec_conv(P, "b%d.c2.dgrad" % b, d_out, dy1, blk.conv2, 1, mask_x=a1, mask=blk.bn2.eval_affine(),
+                     mask_mul_scale=True, mask_activated=True)
             tsc = None
             if blk.sc is not None:
-                tsc = slot.buf("g.b%d.tsc" % b, xin.shape)
+                tsc = slot.buf("g.b%d.tsc" % b, xact.shape)
                 rec_conv(P, "b%d.sc.dgrad" % b, d_out, tsc, blk.sc, 1)
-            dxin = slot.buf("g.b%d.dx" % b, xin.shape)
-            rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=tsc, mask_x=xin,
-                     mask=blk.bn1.eval_affine(), mask_mul_scale=True, add_post=None if blk.sc is not None else d_out)
+            dxin = slot.buf("g.b%d.dx" % b, xact.shape)
+            rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=tsc, mask_x=xact,
+                     mask=blk.bn1.eval_affine(), mask_mul_scale=True, mask_activated=True,
+                     add_post=None if blk.sc is not None else d_out)
             d_out = dxin
         gimg = slot.buf("g.img", (n, slot.hw, slot.hw, 8))
         rec_conv(P, "stem.dgrad", d_out, gimg, self.stem, 1)

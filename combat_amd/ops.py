@@ -90,13 +90,21 @@ class PackedConv:
 
 def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = None, bias=None, add_pre=None,
               mask_x=None, mask: Optional[Affine] = None, mask_mul_scale=False, add_post=None, tanh_out=False,
-              stats_kind=0, stats=None, xh_mean=None, xh_rstd=None, tile=0) -> ConvArgs:
+              stats_kind=0, stats=None, xh_mean=None, xh_rstd=None, tile=0, act_dst=None,
+              act: Optional[Affine] = None, mask_activated=False) -> ConvArgs:
+    """act_dst / act: second output bf16(lrelu(y * act.scale + act.shift)) of the stored value y (the
+    next layer's eval-mode BatchNorm + ReLU); dst may then be None.  mask_activated: mask_x is such an
+    activation (kept-test mask_x > 0)."""
     a = ConvArgs()
     a.N, a.H, a.W, a.C = src.shape
-    _, a.P, a.Q, a.K = dst.shape
+    _, a.P, a.Q, a.K = (dst if dst is not None else act_dst).shape
     a.R = a.S = pc.R
     a.stride, a.pad, a.mode = pc.stride, pc.pad, mode
-    a.src, a.dst = src.data_ptr(), dst.data_ptr()
+    a.src, a.dst = src.data_ptr(), _p(dst)
+    if act_dst is not None:
+        assert act is not None and act.group_stride == 0
+        a.act_dst, a.act_scale, a.act_shift, a.act_slope = act_dst.data_ptr(), _p(act.scale), _p(act.shift), act.slope
+    a.mask_activated = int(mask_activated)
     if mode == 0:
         a.wpack, a.kpad, a.rows_pad = pc.wf.data_ptr(), pc.kpad_f, pc.rows_f
     else:
@@ -114,7 +122,7 @@ def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = No
     a.xh_mean, a.xh_rstd = _p(xh_mean), _p(xh_rstd)
     a.tile = tile
     # the struct holds raw pointers: keep every tensor alive as long as the struct is
-    a._keepalive = (src, dst, pc, pro, bias, add_pre, mask_x, mask, add_post, stats, xh_mean, xh_rstd)
+    a._keepalive = (src, dst, pc, pro, bias, add_pre, mask_x, mask, add_post, stats, xh_mean, xh_rstd, act_dst, act)
     return a
 
 

@@ -64,7 +64,7 @@ typedef struct combat_conv_args {
     const void *wpack;           /* bf16 [rows_pad][kpad] (rows = K) */
     int32_t kpad;                /* padded reduction length of wpack, multiple of 64 */
     int32_t rows_pad;            /* padded row count of wpack */
-    void *dst;                   /* bf16 */
+    void *dst;                   /* bf16 (may be NULL when act_dst is given) */
     /* prologue on src: v = src*scale[g][c] + shift[g][c] (if pro_scale), then
        v = v > 0 ? v : v*pro_slope (if pro_act); padding stays exactly 0.
        g = image index * pro_group_stride / C  (stride 0: per-channel, BatchNorm;
@@ -79,6 +79,8 @@ typedef struct combat_conv_args {
     const void *mask_x;          /* bf16 dst-shaped: q = mask_x*mask_scale[g][n] + mask_shift[g][n];
                                     v *= (q > 0 ? 1 : mask_slope)                 (may be NULL) */
     const float *mask_scale, *mask_shift;   /* NULL scale => q = mask_x */
+    int32_t mask_activated;      /* mask_x already holds the activation (act_dst of the forward pass):
+                                    q = mask_x; mask_scale is then only the mask_mul_scale factor */
     int32_t mask_group_stride;
     float mask_slope;
     int32_t mask_mul_scale;      /* also v *= mask_scale[g][n] (eval-mode BatchNorm backward) */
@@ -90,6 +92,13 @@ typedef struct combat_conv_args {
     int32_t stats_kind;
     float *stats;
     const float *xh_mean, *xh_rstd;         /* group stride = mask_group_stride */
+    /* second output (may be NULL): what the NEXT layer's prologue would compute from the stored value
+       y = bf16(v), so that the next convolution needs no prologue (eval-mode BatchNorm + ReLU, whose
+       scale/shift are known before this layer runs: preact_resnet.py:33,36):
+       act_dst[m][n] = bf16(lrelu(y * act_scale[n] + act_shift[n], act_slope)) */
+    void *act_dst;
+    const float *act_scale, *act_shift;
+    float act_slope;
     int32_t tile;                /* 0 = auto; else a COMBAT_TILE_* value */
 } combat_conv_args;
 

@@ -136,6 +136,50 @@ def test_conv3x3_dma_forward_and_dgrad(ops, n, hw, c, k, tile):
     assert rel_l2(nchw(dx), torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1)) < 4e-3
 
 
+@pytest.mark.parametrize("n,hw,c,k,r,stride,tile,keep_raw", [
+    (4, 16, 64, 64, 3, 1, 0, True), (4, 16, 64, 128, 3, 1, 0, False),     # DMA-staged kernel
+    (4, 16, 64, 64, 3, 1, 8, False), (3, 8, 128, 128, 3, 1, 9, True),     # halo kernels
+    (4, 16, 64, 128, 3, 2, 0, False), (4, 16, 8, 64, 3, 1, 0, True), (4, 16, 64, 128, 1, 2, 0, True)])  # gather kernel
+def test_conv_activation_output_and_activated_mask(ops, n, hw, c, k, r, stride, tile, keep_raw):
+    """Second epilogue output = the next layer's eval BatchNorm + ReLU applied to the stored value
+    (bit-identical to what that layer's prologue would compute), with or without the raw tensor; and
+    the input-gradient mask taken from such an activated tensor (kept-test x > 0, scale multiplies)."""
+    pad = 1 if r == 3 else 0
+    x = torch.randn(n, c, hw, hw, generator=g(1))
+    w, pc = make_conv(ops, k, c, r, stride, pad, 2)
+    p, q = pc.out_hw(hw, hw)
+    sc = (torch.rand(k, generator=g(4)) + 0.5) * torch.where(torch.rand(k, generator=g(7)) < 0.2, -1.0, 1.0)
+    sh = torch.randn(k, generator=g(5)) * 0.3
+    aff = ops.Affine(sc.cuda(), sh.cuda(), 0, True, 0.0)
+    y = torch.empty(n, p, q, k, dtype=bf16, device="cuda") if keep_raw else None
+    act = torch.empty(n, p, q, k, dtype=bf16, device="cuda")
+    ops.conv_launch(ops.conv_args(nhwc(x), y, pc, 0, act_dst=act, act=aff, tile=tile))
+    y_ref = rb(F.conv2d(rb(x), rb(w), stride=stride, padding=pad))
+    if keep_raw:
+        assert rel_l2(nchw(y), y_ref) < 4e-3
+        stored = nchw(y)
+    else:
+        stored = y_ref
+    # fused multiply-add (one rounding), as the kernels' prologue / activation epilogue compute it
+    fma = (stored.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).float()
+    act_ref = rb(torch.relu(fma))
+    if keep_raw:   # exact: the activation is computed from the stored bf16 value
+        assert (nchw(act) != act_ref).sum().item() <= 2
+    else:
+        assert rel_l2(nchw(act), act_ref) < 6e-3
+    if r == 3 and stride == 1 and c >= 64:
+        dy = torch.randn(n, k, hw, hw, generator=g(3))
+        xact = rb(torch.relu(torch.randn(n, c, hw, hw, generator=g(8))))
+        msc = torch.rand(c, generator=g(9)) - 0.3
+        maff = ops.Affine(msc.cuda(), torch.zeros(c).cuda(), 0, True, 0.0)
+        dx = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+        ops.conv_launch(ops.conv_args(nhwc(dy), dx, pc, 1, mask_x=nhwc(xact), mask=maff, mask_mul_scale=True,
+                                      mask_activated=True, tile=tile if c == k else 0))
+        ref = torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1)
+        ref = ref * (xact > 0).float() * msc.view(1, -1, 1, 1)
+        assert rel_l2(nchw(dx), ref) < 4e-3
+
+
 @pytest.mark.parametrize("n,hw,c,groups_per_image,tile", [(4, 32, 64, True, 0), (3, 8, 128, True, 0), (8, 4, 128, True, 9),
                                                         (8, 4, 128, False, 0)])
 def test_conv3x3_halo_instance_stats_layout(ops, n, hw, c, groups_per_image, tile):
