@@ -33,6 +33,12 @@ struct ConvParams {
     int s_shift;  // log2(stride)
     int nkt;      // reduction steps of 64
     int tiles_m, tiles_n;
+    // stride-2 input-gradient passes: destination pixels are enumerated parity-class-major
+    // [(oy & 1, ox & 1)][image][oy >> 1][ox >> 1], so that a tile's pixels all see the same 1, 2 or 4
+    // filter taps (of 9) and the others are skipped instead of being gathered as zeros
+    int psplit;   // 0 / 1
+    int mq;       // pixels per parity class (M / 4)
+    int cpt;      // 64-channel chunks per tap (C / 64)
 };
 
 __device__ __forceinline__ int lds_off(int row, int kchunk) { return row * 128 + ((kchunk ^ ((row >> 1) & 7)) << 4); }
@@ -62,13 +68,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 
     // ---- per-thread gather bookkeeping: this thread always stages the same rows / k-chunk
     const int a_chunk = tid & 7, a_row0 = tid >> 3;
+    // parity-class-major pixel order (psplit): class of this tile, its valid taps (4 bits each) and count
+    int pcls = 0, taplist = 0, ntap_valid = 0;
+    if (p.psplit) {
+        pcls = m0 / p.mq;
+        const int py = pcls >> 1, px = pcls & 1;   // tap r is valid iff (oy + pad - r) is even
+        const int r0 = (py + a.pad) & 1, s0 = (px + a.pad) & 1;
+        for (int r = r0; r < a.R; r += 2)
+            for (int sx = s0; sx < a.S; sx += 2) taplist |= (r * a.S + sx) << (4 * ntap_valid++);
+    }
+    auto decode = [&](int m, int &img, int &oy, int &ox) {
+        if (p.psplit) {
+            const int rem = m - pcls * p.mq, q4 = p.PQ >> 2, hq = a.Q >> 1;
+            img = rem / q4;
+            const int r2 = rem - img * q4, yy = r2 / hq;
+            oy = 2 * yy + (pcls >> 1);
+            ox = 2 * (r2 - yy * hq) + (pcls & 1);
+        } else {
+            img = m / p.PQ;
+            const int rem = m - img * p.PQ;
+            oy = rem / a.Q;
+            ox = rem - oy * a.Q;
+        }
+    };
     int a_pix[T::A_ITERS], a_by[T::A_ITERS], a_bx[T::A_ITERS], a_g[T::A_ITERS];
 #pragma unroll
     for (int i = 0; i < T::A_ITERS; ++i) {
         const int m = m0 + a_row0 + 32 * i;
         if (m < p.M) {
-            const int img = m / p.PQ, rem = m - img * p.PQ;
-            const int oy = rem / a.Q, ox = rem - oy * a.Q;
+            int img, oy, ox;
+            decode(m, img, oy, ox);
             a_pix[i] = img * H * W;
             a_g[i] = img * a.pro_group_stride;
             if (a.mode == 0) {
@@ -93,9 +122,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const bool pro_affine = a.pro_scale != nullptr;
     const bool pro_shared = pro_affine && a.pro_group_stride == 0;
 
+    // reduction step kt -> (filter tap, first channel of this thread's chunk, k offset of the weight step)
+    auto step_of = [&](int kt, int &tap, int &ci, int &wk) {
+        if (p.psplit) {
+            const int j = kt / p.cpt, cc = kt - j * p.cpt;
+            tap = (taplist >> (4 * j)) & 15;
+            ci = cc * 64 + a_chunk * 8;
+            wk = tap * C + cc * 64;
+        } else {
+            const int kbase = kt * 64 + a_chunk * 8;
+            tap = kbase >> p.c_shift;
+            ci = kbase & (C - 1);
+            wk = kt * 64;
+        }
+    };
+    const int nkt = p.psplit ? ntap_valid * p.cpt : p.nkt;
+
     auto load_tile = [&](int kt) {
-        const int kbase = kt * 64 + a_chunk * 8;
-        const int tap = kbase >> p.c_shift, ci = kbase & (C - 1);
+        int tap, ci, wk;
+        step_of(kt, tap, ci, wk);
         const int r = (a.S == 3) ? ((tap * 11) >> 5) : tap;
         const int s = tap - r * a.S;
         const bool tap_ok = tap < p.ntaps;
@@ -125,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (b_active) {
 #pragma unroll
             for (int j = 0; j < T::B_ITERS; ++j)
-                rb[j] = *reinterpret_cast<const u32x4_t *>(b_ptr + (size_t)(32 * j) * a.kpad + kt * 64);
+                rb[j] = *reinterpret_cast<const u32x4_t *>(b_ptr + (size_t)(32 * j) * a.kpad + wk);
         }
         if (pro_shared && tap_ok) {
             load8f(a.pro_scale + ci, pscale);
@@ -136,7 +181,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     auto store_tile = [&](int kt, int buf) {
         unsigned char *al = smem + buf * (BM * 128);
         unsigned char *bl = smem + 2 * (BM * 128) + buf * (BN * 128);
-        const int ci = (kt * 64 + a_chunk * 8) & (C - 1);
+        int tap_, ci, wk_;
+        step_of(kt, tap_, ci, wk_);
 #pragma unroll
         for (int i = 0; i < T::A_ITERS; ++i) {
             uint4 val = ra[i];
@@ -207,8 +253,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     load_tile(0);
     store_tile(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < p.nkt; ++kt) {
-        const bool more = kt + 1 < p.nkt;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
         if (more) load_tile(kt + 1);
         compute(kt & 1);
         if (more) store_tile(kt + 1, (kt + 1) & 1);
@@ -218,9 +264,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     // ---- epilogue (shared with the halo kernel)
     {
         const int gi = m0 / T::SG + wid;
-        conv_epilogue<T>(smem, acc, a, n0, p.PQ, [&](int row) { const int m = m0 + row; return m < p.M ? m : -1; },
+        conv_epilogue<T>(smem, acc, a, n0, p.PQ,
+                         [&](int row) {
+                             const int m = m0 + row;
+                             if (m >= p.M) return -1;
+                             if (!p.psplit) return m;
+                             int img, oy, ox;
+                             decode(m, img, oy, ox);
+                             return (img * a.P + oy) * a.Q + ox;
+                         },
                          gi * T::SG < p.M ? gi : -1);
     }
+}
+
+// stride-2 input-gradient passes whose statistics (if any) are per-channel: pixels may be enumerated
+// parity-class-major (the statistics rows are then not image-aligned)
+bool parity_split(const combat_conv_args &a) {
+    return a.mode == 1 && a.stride == 2 && (a.P & 1) == 0 && (a.Q & 1) == 0 && (a.C & 63) == 0 && a.R <= 3 &&
+           (a.stats_kind == 0 || a.mask_group_stride == 0) && a.pro_group_stride == 0;
 }
 
 template <int BM, int BN>
@@ -237,6 +298,9 @@ int launch(const ConvParams &p, hipStream_t st) {
     ConvParams q = p;
     q.tiles_m = (p.M + BM - 1) / BM;
     q.tiles_n = (p.a.K + BN - 1) / BN;
+    q.psplit = parity_split(p.a) && (p.M / 4) % BM == 0;
+    q.mq = p.M / 4;
+    q.cpt = p.a.C / 64;
     if (q.tiles_n * BN > p.a.rows_pad) return COMBAT_EINVAL;
     hipLaunchKernelGGL(kern, dim3(q.tiles_m * q.tiles_n), dim3(256), T::SMEM, st, q);
     CB_LAUNCH_CHECK();
@@ -284,6 +348,8 @@ extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows
     const long M = (long)a->N * a->P * a->Q, PQ = (long)a->P * a->Q;
     *rows = (int)((M + gran - 1) / gran);
     *rows_per_image = (PQ % gran == 0) ? (int)(PQ / gran) : 0;
+    const int bm = (tile == COMBAT_TILE_64x64 || tile == COMBAT_TILE_64x128) ? 64 : 128;
+    if (parity_split(*a) && (M / 4) % bm == 0) *rows_per_image = 0;   // parity-class-major pixel order
     return COMBAT_OK;
 }
 

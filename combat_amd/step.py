@@ -183,11 +183,12 @@ class AlternatedStep:
         self._gen_small: Dict[int, tuple] = {}
 
     def _small(self, nbk: int):
-        """Generator slot + plan for a poisoned sub-batch bucket."""
+        """Buffers of a poisoned sub-batch bucket: fp32 images, their generator outputs, c8 scratch."""
         if nbk not in self._gen_small:
-            s = self.eG.slot("G.small", nbk, self.hw)
-            self._gen_small[nbk] = (s, self.eG.forward_plan(s),
-                                    torch.zeros(nbk, 3, self.hw, self.hw, dtype=f32, device=self.dev))
+            hw = self.hw
+            self._gen_small[nbk] = (torch.zeros(nbk, 3, hw, hw, dtype=f32, device=self.dev),
+                                    torch.zeros(nbk, hw, hw, 8, dtype=torch.bfloat16, device=self.dev),
+                                    torch.zeros(nbk, hw, hw, 8, dtype=torch.bfloat16, device=self.dev))
         return self._gen_small[nbk]
 
     # ------------------------------------------------------------------ one step
@@ -237,14 +238,22 @@ class AlternatedStep:
         rate = float(opt.noise_rate)
         x_ptr = self.inputs.data_ptr()
 
+        # ---- generator forward of the whole batch, ONCE for both phases.  The reference runs netG twice
+        # (train_generator.py:187 on the poisoned images in eval mode, :216 on the batch in train mode);
+        # the UNet has InstanceNorm without running statistics and no dropout, and its weights only
+        # change at the end of Phase G, so the first call's outputs are rows of the second's.
+        ops.check(lib.combat_image_to_c8(x_ptr, n, hw, eG.input(self.sG).data_ptr(), st), "c8 G")
+        pl["G_f"].run(prof)
+        noise = eG.output(self.sG)
+
         # ================= Phase C (train_generator.py:175-212) =================
         if nb:
             nbk = min(bucket(nb), n)
-            sS, plan_small, tochange = self._small(nbk)
-            ops.check(lib.combat_augment_fwd(x_ptr, self.tab_i[0].data_ptr(), None, nbk, hw, eG.input(sS).data_ptr(),
+            tochange, noise_small, c8_scratch = self._small(nbk)
+            ops.check(lib.combat_augment_fwd(x_ptr, self.tab_i[0].data_ptr(), None, nbk, hw, c8_scratch.data_ptr(),
                                              tochange.data_ptr(), st), "gather poisoned")
-            plan_small.run(prof)
-            ops.check(lib.combat_trigger_fwd(tochange.data_ptr(), eG.output(sS).data_ptr(), P_, k1c, rate, nb, hw,
+            torch.index_select(noise, 0, self.tab_i[0][:nbk], out=noise_small)
+            ops.check(lib.combat_trigger_fwd(tochange.data_ptr(), noise_small.data_ptr(), P_, k1c, rate, nb, hw,
                                              self.cat_src[n:].data_ptr(), None, None, st), "trigger C")
         ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(), aug_ptr[0], n, hw,
                                          eC.input(self.sC_train).data_ptr(), None, st), "augment 0")
@@ -256,10 +265,7 @@ class AlternatedStep:
         xK, xC = eK.input(self.sK_eval), eC.input(self.sC_eval)     # [2n, hw, hw, 8]: metric half, loss half
         ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[1], n, hw, xK.data_ptr(), None, st), "augment 1")  # :214
 
-        # ================= Phase G (train_generator.py:216-255) =================
-        ops.check(lib.combat_image_to_c8(x_ptr, n, hw, eG.input(self.sG).data_ptr(), st), "c8 G")
-        pl["G_f"].run(prof)
-        noise = eG.output(self.sG)
+        # ================= Phase G (train_generator.py:216-255; its generator forward ran above) =================
         ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.bd.data_ptr(), None,
                                          self.mse.data_ptr(), st), "trigger G")
         bd_ptr = self.bd.data_ptr()

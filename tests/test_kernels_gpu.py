@@ -307,6 +307,33 @@ def test_conv_dgrad_and_wgrad(ops, n, hw, c, k, r, stride, pad):
     assert rel_l2(dw, ref) < 2e-3
 
 
+@pytest.mark.parametrize("n,hw,c,k,r", [(8, 16, 64, 128, 3), (16, 8, 256, 512, 3), (8, 16, 128, 256, 1), (3, 8, 64, 64, 3)])
+def test_conv_stride2_dgrad_parity_classes(ops, n, hw, c, k, r):
+    """Input gradient of a stride-2 convolution: destination pixels are walked parity-class-major so
+    that invalid filter taps are skipped; mask, scale and per-channel statistics in the epilogue must
+    not care (the last case's class size is not a multiple of the tile: linear order)."""
+    pad = 1 if r == 3 else 0
+    w, pc = make_conv(ops, k, c, r, 2, pad, 40)
+    p = hw // 2
+    dy = torch.randn(n, k, p, p, generator=g(41))
+    xpre = torch.randn(n, c, hw, hw, generator=g(42))
+    sc = torch.rand(c, generator=g(43)) - 0.3
+    sh = torch.randn(c, generator=g(44)) * 0.3
+    ref = torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), stride=2, padding=pad)
+    ref = ref * ((rb(xpre) * sc[None, :, None, None] + sh[None, :, None, None]) > 0).float() * sc[None, :, None, None]
+    dx = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(dy), dx, pc, 1, mask_x=nhwc(xpre), mask=ops.Affine(dev(sc), dev(sh), 0, True, 0.0),
+                      mask_mul_scale=True, stats_kind=1)
+    rows, _ = ops.conv_stats_layout(a)
+    stats = torch.zeros(rows, 2, c, device="cuda")
+    a.stats = stats.data_ptr()
+    ops.conv_launch(a)
+    assert rel_l2(nchw(dx), ref) < 4e-3
+    got = nchw(dx)
+    assert rel_l2(stats.sum(0).cpu()[0], got.sum((0, 2, 3))) < 1e-4
+    assert rel_l2(stats.sum(0).cpu()[1], (got * got).sum((0, 2, 3))) < 1e-4
+
+
 def test_conv_dgrad_epilogue_mask_stats(ops):
     """Train-mode BN backward, reduction half fused into dgrad: dz = (dgrad + add_pre) * relu'(bn(x)),
     partial sums of dz and dz*xhat; eval-mode variant multiplies by the BN scale and adds the
