@@ -48,6 +48,21 @@ class WgradArgs(C.Structure):
     ]
 
 
+class PackDesc(C.Structure):
+    """struct combat_pack_desc"""
+
+    _fields_ = [("w", c_vp), ("wf", c_vp), ("wd", c_vp),
+                ("K", c_i32), ("taps", c_i32), ("c_real", c_i32), ("C", c_i32), ("dup_hilo", c_i32),
+                ("rows_pad_f", c_i32), ("kpad_f", c_i32), ("rows_pad_d", c_i32), ("kpad_d", c_i32), ("reserved", c_i32)]
+
+
+class BnDesc(C.Structure):
+    """struct combat_bn_desc"""
+
+    _fields_ = [("gamma", c_vp), ("beta", c_vp), ("running_mean", c_vp), ("running_var", c_vp),
+                ("scale", c_vp), ("shift", c_vp), ("C", c_i32), ("reserved", c_i32)]
+
+
 # name -> (restype, argtypes); one entry per function declared in include/combat_hip.h
 SIGNATURES = {
     "combat_version": (C.c_char_p, []),
@@ -63,6 +78,8 @@ SIGNATURES = {
                                        c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp]),
     "combat_norm_scratch_bytes": (c_i64, [c_i32, c_i32]),
     "combat_bn_eval_fold": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp, c_vp]),
+    "combat_pack_weights_batch": (C.c_int, [c_vp, c_i32, c_vp]),
+    "combat_bn_eval_fold_batch": (C.c_int, [c_vp, c_i32, c_f32, c_vp]),
     "combat_group_stats": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_norm_bwd_finalize": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_vp, c_vp, c_i64, c_vp]),

@@ -36,6 +36,38 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
     }
 }
 
+// every convolution of a network: blockIdx.y = descriptor
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const combat_pack_desc *__restrict__ descs) {
+    const combat_pack_desc d = descs[blockIdx.y];
+    const float *__restrict__ w = d.w;
+    __bf16 *__restrict__ wf = reinterpret_cast<__bf16 *>(d.wf);
+    __bf16 *__restrict__ wd = reinterpret_cast<__bf16 *>(d.wd);
+    const int K = d.K, taps = d.taps, creal = d.c_real, C = d.C, Kc = (d.K + 7) & ~7;
+    const long nf = (long)d.rows_pad_f * d.kpad_f;
+    const long nd = wd ? (long)d.rows_pad_d * d.kpad_d : 0;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nf + nd; t += (long)gridDim.x * blockDim.x) {
+        if (t < nf) {
+            const int n = (int)(t / d.kpad_f), k = (int)(t - (long)n * d.kpad_f);
+            const int tap = k / C, c = k - tap * C;
+            float v = 0.f;
+            if (n < K && tap < taps) {
+                int cm = -1;
+                if (c < creal) cm = c;
+                else if (d.dup_hilo && c < 2 * creal) cm = c - creal;
+                if (cm >= 0) v = w[((long)n * taps + tap) * creal + cm];
+            }
+            wf[t] = (__bf16)v;
+        } else {
+            const long u = t - nf;
+            const int c = (int)(u / d.kpad_d), k = (int)(u - (long)c * d.kpad_d);
+            const int tap = k / Kc, n = k - tap * Kc;
+            float v = 0.f;
+            if (c < creal && tap < taps && n < K) v = w[((long)n * taps + tap) * creal + c];
+            wd[u] = (__bf16)v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ image layout
 __device__ __forceinline__ uint4 hilo_pixel(float r, float g, float b) {
     const float hr = round_bf16(r), hg = round_bf16(g), hb = round_bf16(b);
@@ -334,6 +366,14 @@ extern "C" int combat_pack_weights(const float *w, int32_t K, int32_t taps, int3
     hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, K, taps, c_real,
                        C, dup_hilo, reinterpret_cast<__bf16 *>(wf), rows_pad_f, kpad_f, reinterpret_cast<__bf16 *>(wd),
                        rows_pad_d, kpad_d, Kc);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_pack_weights_batch(const combat_pack_desc *descs, int32_t n, void *stream) {
+    if (!descs || n < 0) return COMBAT_EINVAL;
+    if (n == 0) return COMBAT_OK;
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(96, (unsigned)n), dim3(256), 0, as_stream(stream), descs);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -127,6 +127,15 @@ __global__ void bn_eval_fold_kernel(const float *gamma, const float *beta, const
     shift[c] = beta[c] - rm[c] * s;
 }
 
+__global__ void bn_eval_fold_batch_kernel(const combat_bn_desc *__restrict__ descs, float eps) {
+    const combat_bn_desc d = descs[blockIdx.y];
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d.C; c += gridDim.x * blockDim.x) {
+        const float s = d.gamma[c] / sqrtf(d.running_var[c] + eps);
+        d.scale[c] = s;
+        d.shift[c] = d.beta[c] - d.running_mean[c] * s;
+    }
+}
+
 // one thread per (part, 8-channel chunk); a part is a run of <= 64 rows (a whole small
 // InstanceNorm group, or a 32-row slab of a larger one -- same layout as the conv epilogue's)
 __global__ __launch_bounds__(256) void group_stats_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dz,
@@ -275,6 +284,14 @@ extern "C" int combat_bn_eval_fold(const float *gamma, const float *beta, const 
     if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return COMBAT_EINVAL;
     hipLaunchKernelGGL(bn_eval_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta,
                        running_mean, running_var, eps, C, scale, shift);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_bn_eval_fold_batch(const combat_bn_desc *descs, int32_t n, float eps, void *stream) {
+    if (!descs || n < 0) return COMBAT_EINVAL;
+    if (n == 0) return COMBAT_OK;
+    hipLaunchKernelGGL(bn_eval_fold_batch_kernel, dim3(2, (unsigned)n), dim3(256), 0, as_stream(stream), descs, eps);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -12,32 +12,56 @@
 
 namespace {
 
-// C[i][j] = sum_k A[i][k] * B[k][j]  (tb: use B[j][k]; ta: use A[k][i]); all hw x hw fp32 in LDS
-template <bool TA, bool TB>
-__device__ __forceinline__ void mm(const float *A, const float *B, float *Cm, int hw, int tid, int nthr) {
-    for (int o = tid; o < hw * hw; o += nthr) {
-        const int i = o / hw, j = o - i * hw;
-        float s = 0.f;
+// ---- dense hw x hw fp32 products in LDS, 256 threads.  A thread owns 4 consecutive outputs of one row:
+// per k one (broadcast) scalar of the left operand and one float4 of the right operand feed 4 FMAs.
+// The left operand has row pitch LP (hw + 1 keeps the 8 rows a wave touches on distinct banks), the
+// right operand pitch hw; the output pitch OP is chosen by what the result is used as next.  The
+// k-order is ascending with one fma per term, as a plain dot-product loop.
+__device__ __forceinline__ void mm4(const float *__restrict__ L, int LP, const float *__restrict__ Rm,
+                                    float *__restrict__ O, int OP, int hw, int tid) {
+    const int q = hw >> 2;
+    for (int o = tid; o < hw * q; o += 256) {
+        const int i = o / q, j0 = (o - i * q) << 2;
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f};
+        const float *lp = L + i * LP;
         for (int k = 0; k < hw; ++k) {
-            const float av = TA ? A[k * hw + i] : A[i * hw + k];
-            const float bv = TB ? B[j * hw + k] : B[k * hw + j];
-            s = fmaf(av, bv, s);
+            const float a = lp[k];
+            const f32x4_t b = *reinterpret_cast<const f32x4_t *>(Rm + k * hw + j0);
+            s[0] = fmaf(a, b[0], s[0]);
+            s[1] = fmaf(a, b[1], s[1]);
+            s[2] = fmaf(a, b[2], s[2]);
+            s[3] = fmaf(a, b[3], s[3]);
         }
-        Cm[o] = s;
+        float *op = O + i * OP + j0;
+        op[0] = s[0]; op[1] = s[1]; op[2] = s[2]; op[3] = s[3];
     }
 }
 
-// reflect-padded 3-tap blur as a matrix: out[i] = k0*in[r(i-1)] + k1*in[i] + k2*in[r(i+1)]
-__device__ __forceinline__ void build_blur(float *Kb, const float *k1, int hw, int tid, int nthr) {
-    for (int o = tid; o < hw * hw; o += nthr) Kb[o] = 0.f;
-    __syncthreads();
-    for (int i = tid; i < hw; i += nthr) {
-        const int im = i > 0 ? i - 1 : 1, ip = i + 1 < hw ? i + 1 : hw - 2;
-        Kb[i * hw + im] += k1[0];
-        Kb[i * hw + i] += k1[1];
-        Kb[i * hw + ip] += k1[2];
+// entry (i, k) of the reflect-padded 3-tap blur matrix: out[i] = k0*in[r(i-1)] + k1*in[i] + k2*in[r(i+1)]
+__device__ __forceinline__ float blur_coef(const float (&kk)[3], int hw, int i, int k) {
+    const int im = i > 0 ? i - 1 : 1, ip = i + 1 < hw ? i + 1 : hw - 2;
+    float c = 0.f;
+    if (k == im) c += kk[0];
+    if (k == i) c += kk[1];
+    if (k == ip) c += kk[2];
+    return c;
+}
+
+// Kb * X (ROWS) or X * Kb^T (!ROWS), or with the transposed matrix (TR): three-term stencils evaluated in
+// ascending index order, i.e. the dense product's fma chain without its zero terms.
+template <bool ROWS, bool TR>
+__device__ __forceinline__ void blur_pass(const float *__restrict__ X, float *__restrict__ O, const float (&kk)[3],
+                                          int hw, int tid) {
+    for (int o = tid; o < hw * hw; o += 256) {
+        const int i = o / hw, j = o - i * hw;
+        const int t = ROWS ? i : j;            // the blurred index
+        float s = 0.f;
+        for (int k = t > 0 ? t - 1 : 0; k <= (t + 1 < hw ? t + 1 : hw - 1); ++k) {
+            const float c = TR ? blur_coef(kk, hw, k, t) : blur_coef(kk, hw, t, k);
+            s = fmaf(c, ROWS ? X[k * hw + j] : X[i * hw + k], s);
+        }
+        O[o] = s;
     }
-    __syncthreads();
 }
 
 __device__ __forceinline__ uint4 hilo_px(float r, float g, float b) {
@@ -50,106 +74,113 @@ __device__ __forceinline__ uint4 hilo_px(float r, float g, float b) {
     return u;
 }
 
-// dynamic LDS: P, Kb, two scratch planes A/B, three result planes R (7 * hw*hw floats)
+__device__ __forceinline__ void store_hilo(__bf16 *px8, int c, float v) {   // hi/lo halves of channel c of a c8 pixel
+    const float h = round_bf16(v);
+    px8[c] = (__bf16)h;
+    px8[3 + c] = (__bf16)(v - h);
+    if (c == 0) *reinterpret_cast<unsigned int *>(px8 + 6) = 0u;
+}
+
+// One workgroup per (channel, image): 3n workgroups.  LDS (floats): Pl [hw][hw+1], Pr [hw][hw], A [hw][hw],
+// B [hw][hw+1].  P is symmetric (D^T diag(mask) D), so P N P^T = (P N) P needs no transposed operand.
 __global__ __launch_bounds__(256) void trigger_fwd_kernel(const float *__restrict__ x, const __bf16 *__restrict__ noise,
                                                           const float *__restrict__ P, const float *__restrict__ k1,
                                                           float rate, int hw, float *__restrict__ out,
-                                                          uint4 *__restrict__ out_c8, float *__restrict__ mse) {
+                                                          __bf16 *__restrict__ out_c8, float *__restrict__ mse) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hw2 = hw * hw, tid = threadIdx.x, img = blockIdx.x;
-    float *Pm = sm, *Kb = sm + hw2, *A = sm + 2 * hw2, *B = sm + 3 * hw2, *R = sm + 4 * hw2;
-    for (int o = tid; o < hw2; o += 256) Pm[o] = P[o];
-    build_blur(Kb, k1, hw, tid, 256);
-    const float *xi = x + (long)img * 3 * hw2;
-    for (int c = 0; c < 3; ++c) {
-        for (int o = tid; o < hw2; o += 256)
-            A[o] = (float)noise[((long)img * hw2 + o) * 8 + c];
-        __syncthreads();
-        mm<false, false>(Pm, A, B, hw, tid, 256);  // P * N
-        __syncthreads();
-        mm<false, true>(B, Pm, A, hw, tid, 256);   // (P N) * P^T
-        __syncthreads();
-        for (int o = tid; o < hw2; o += 256) A[o] = fminf(fmaxf(fmaf(A[o], rate, xi[c * hw2 + o]), -1.f), 1.f);
-        __syncthreads();
-        mm<false, false>(Kb, A, B, hw, tid, 256);  // Kb * bd
-        __syncthreads();
-        mm<false, true>(B, Kb, R + c * hw2, hw, tid, 256);  // ... * Kb^T
-        __syncthreads();
+    const int hw2 = hw * hw, lp = hw + 1, tid = threadIdx.x, c = blockIdx.x, img = blockIdx.y;
+    float *Pl = sm, *Pr = Pl + hw * lp, *A = Pr + hw2, *B = A + hw2;
+    const float kk[3] = {k1[0], k1[1], k1[2]};
+    const float *xi = x + ((long)img * 3 + c) * hw2;
+    for (int o = tid; o < hw2; o += 256) {
+        const float pv = P[o];
+        Pr[o] = pv;
+        Pl[(o / hw) * lp + (o % hw)] = pv;
+        A[o] = (float)noise[((long)img * hw2 + o) * 8 + c];
     }
+    __syncthreads();
+    mm4(Pl, lp, A, B, lp, hw, tid);            // B = P N
+    __syncthreads();
+    mm4(B, lp, Pr, A, hw, hw, tid);            // A = (P N) P
+    __syncthreads();
+    for (int o = tid; o < hw2; o += 256) A[o] = fminf(fmaxf(fmaf(A[o], rate, xi[o]), -1.f), 1.f);
+    __syncthreads();
+    blur_pass<true, false>(A, B, kk, hw, tid);   // Kb * bd
+    __syncthreads();
+    blur_pass<false, false>(B, A, kk, hw, tid);  // ... * Kb^T
+    __syncthreads();
     float se = 0.f;
-    for (int o = tid; o < 3 * hw2; o += 256) {
-        const float v = R[o];
-        out[(long)img * 3 * hw2 + o] = v;
+    for (int o = tid; o < hw2; o += 256) {
+        const float v = A[o];
+        out[((long)img * 3 + c) * hw2 + o] = v;
         const float d = v - xi[o];
         se = fmaf(d, d, se);
+        if (out_c8) store_hilo(out_c8 + ((long)img * hw2 + o) * 8, c, v);
     }
-    if (out_c8)
-        for (int o = tid; o < hw2; o += 256) out_c8[(long)img * hw2 + o] = hilo_px(R[o], R[hw2 + o], R[2 * hw2 + o]);
     if (mse) {
-        A[tid] = se;
+        __syncthreads();
+        B[tid] = se;
         __syncthreads();
         for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) A[tid] += A[tid + s];
+            if (tid < s) B[tid] += B[tid + s];
             __syncthreads();
         }
-        if (tid == 0) mse[img] = A[0];
+        if (tid == 0) mse[img * 3 + c] = B[0];
     }
 }
 
 // d_noise = rate * P * ( clampmask .* (Kb^T * (d_out + 2*l2*(out-x)) * Kb) ) * P      (P symmetric)
-// dynamic LDS: P, Kb, scratch A/B/G, results R (8 * hw*hw floats)
+// LDS (floats): Pl, Pr, A, B as above + G [hw][hw]
 __global__ __launch_bounds__(256) void trigger_bwd_kernel(const float *__restrict__ x, const __bf16 *__restrict__ noise,
                                                           const float *__restrict__ P, const float *__restrict__ k1,
                                                           float rate, int hw, const float *__restrict__ d_out,
                                                           const float *__restrict__ outp, float l2_scale,
-                                                          int pre_tanh, uint4 *__restrict__ d_noise) {
+                                                          int pre_tanh, __bf16 *__restrict__ d_noise) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hw2 = hw * hw, tid = threadIdx.x, img = blockIdx.x;
-    float *Pm = sm, *Kb = sm + hw2, *A = sm + 2 * hw2, *B = sm + 3 * hw2, *G = sm + 4 * hw2, *R = sm + 5 * hw2;
-    for (int o = tid; o < hw2; o += 256) Pm[o] = P[o];
-    build_blur(Kb, k1, hw, tid, 256);
-    const float *xi = x + (long)img * 3 * hw2;
-    for (int c = 0; c < 3; ++c) {
-        for (int o = tid; o < hw2; o += 256) {
-            A[o] = (float)noise[((long)img * hw2 + o) * 8 + c];
-            const long go = ((long)img * 3 + c) * hw2 + o;
-            float g = d_out ? d_out[go] : 0.f;
-            if (l2_scale != 0.f) g = fmaf(2.f * l2_scale, outp[go] - xi[c * hw2 + o], g);
-            G[o] = g;
-        }
-        __syncthreads();
-        mm<false, false>(Pm, A, B, hw, tid, 256);
-        __syncthreads();
-        mm<false, true>(B, Pm, A, hw, tid, 256);   // A = P N P^T  (pre-clamp value needs x + rate*A)
-        __syncthreads();
-        mm<true, false>(Kb, G, B, hw, tid, 256);   // B = Kb^T g
-        __syncthreads();
-        mm<false, false>(B, Kb, G, hw, tid, 256);  // G = Kb^T g Kb
-        __syncthreads();
-        for (int o = tid; o < hw2; o += 256) {
-            const float v = fmaf(A[o], rate, xi[c * hw2 + o]);
-            G[o] = (v >= -1.f && v <= 1.f) ? G[o] * rate : 0.f;
-        }
-        __syncthreads();
-        mm<false, false>(Pm, G, B, hw, tid, 256);
-        __syncthreads();
-        mm<false, false>(B, Pm, R + c * hw2, hw, tid, 256);  // P g P
-        __syncthreads();
-    }
+    const int hw2 = hw * hw, lp = hw + 1, tid = threadIdx.x, c = blockIdx.x, img = blockIdx.y;
+    float *Pl = sm, *Pr = Pl + hw * lp, *A = Pr + hw2, *B = A + hw2, *G = B + hw * lp;
+    const float kk[3] = {k1[0], k1[1], k1[2]};
+    const float *xi = x + ((long)img * 3 + c) * hw2;
     for (int o = tid; o < hw2; o += 256) {
-        uint4 u;
+        const float pv = P[o];
+        Pr[o] = pv;
+        Pl[(o / hw) * lp + (o % hw)] = pv;
+        A[o] = (float)noise[((long)img * hw2 + o) * 8 + c];
+        const long go = ((long)img * 3 + c) * hw2 + o;
+        float g = d_out ? d_out[go] : 0.f;
+        if (l2_scale != 0.f) g = fmaf(2.f * l2_scale, outp[go] - xi[o], g);
+        G[o] = g;
+    }
+    __syncthreads();
+    mm4(Pl, lp, A, B, lp, hw, tid);
+    __syncthreads();
+    mm4(B, lp, Pr, A, hw, hw, tid);              // A = P N P  (pre-clamp value is x + rate*A)
+    __syncthreads();
+    blur_pass<true, true>(G, B, kk, hw, tid);    // B = Kb^T g      (pitch hw: a stencil operand)
+    __syncthreads();
+    blur_pass<false, true>(B, G, kk, hw, tid);   // G = Kb^T g Kb
+    __syncthreads();
+    for (int o = tid; o < hw2; o += 256) {
+        const float v = fmaf(A[o], rate, xi[o]);
+        G[o] = (v >= -1.f && v <= 1.f) ? G[o] * rate : 0.f;
+    }
+    __syncthreads();
+    mm4(Pl, lp, G, B, lp, hw, tid);              // B = P g
+    __syncthreads();
+    mm4(B, lp, Pr, A, hw, hw, tid);              // A = P g P
+    __syncthreads();
+    for (int o = tid; o < hw2; o += 256) {
+        __bf16 *px = d_noise + ((long)img * hw2 + o) * 8;
+        float r = A[o];
         if (pre_tanh) {  // noise = tanh(z): hand back the gradient w.r.t. z
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float t = (float)noise[((long)img * hw2 + o) * 8 + c];
-                R[c * hw2 + o] *= 1.f - t * t;
-            }
+            const float t = (float)noise[((long)img * hw2 + o) * 8 + c];
+            r *= 1.f - t * t;
         }
-        u.x = pack_bf16x2(R[o], R[hw2 + o]);
-        u.y = pack_bf16x2(R[2 * hw2 + o], 0.f);
-        u.z = 0;
-        u.w = 0;
-        d_noise[(long)img * hw2 + o] = u;
+        px[c] = (__bf16)r;
+        if (c == 0) {   // channels 3..7 of the c8 pixel carry no gradient
+            px[3] = (__bf16)0.f;
+            *reinterpret_cast<uint2 *>(px + 4) = make_uint2(0u, 0u);
+        }
     }
 }
 
@@ -260,22 +291,26 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const __bf16 *__restri
 }
 
 // ------------------------------------------------------------------ DCT of the uint8-truncated image
+// one workgroup per (channel, image); LDS (floats): Dl [hw][hw+1] = D, Dr [hw][hw] = D^T, A, B [hw][hw+1]
 __global__ __launch_bounds__(256) void dct_u8_kernel(const float *__restrict__ x, const float *__restrict__ D, int hw,
-                                                     uint4 *__restrict__ out_c8) {
+                                                     __bf16 *__restrict__ out_c8) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int hw2 = hw * hw, tid = threadIdx.x, img = blockIdx.x;
-    float *Dm = sm, *A = sm + hw2, *B = sm + 4 * hw2;
-    for (int o = tid; o < hw2; o += 256) Dm[o] = D[o];
-    for (int o = tid; o < 3 * hw2; o += 256) {
-        const float q = (x[(long)img * 3 * hw2 + o] + 1.f) / 2.f * 255.f;
+    const int hw2 = hw * hw, lp = hw + 1, tid = threadIdx.x, c = blockIdx.x, img = blockIdx.y;
+    float *Dl = sm, *Dr = Dl + hw * lp, *A = Dr + hw2, *B = A + hw2;
+    for (int o = tid; o < hw2; o += 256) {
+        const int i = o / hw, j = o - i * hw;
+        const float dv = D[o];
+        Dl[i * lp + j] = dv;
+        Dr[j * hw + i] = dv;
+        const float q = (x[((long)img * 3 + c) * hw2 + o] + 1.f) / 2.f * 255.f;
         A[o] = (float)(unsigned char)(int)q;  // .byte(): truncate toward zero, wrap mod 256
     }
     __syncthreads();
-    for (int c = 0; c < 3; ++c) mm<false, false>(Dm, A + c * hw2, B + c * hw2, hw, tid, 256);
+    mm4(Dl, lp, A, B, lp, hw, tid);     // B = D q
     __syncthreads();
-    for (int c = 0; c < 3; ++c) mm<false, true>(B + c * hw2, Dm, A + c * hw2, hw, tid, 256);
+    mm4(B, lp, Dr, A, hw, hw, tid);     // A = D q D^T
     __syncthreads();
-    for (int o = tid; o < hw2; o += 256) out_c8[(long)img * hw2 + o] = hilo_px(A[o], A[hw2 + o], A[2 * hw2 + o]);
+    for (int o = tid; o < hw2; o += 256) store_hilo(out_c8 + ((long)img * hw2 + o) * 8, c, A[o]);
 }
 
 template <typename K>
@@ -291,13 +326,13 @@ int set_smem(K kern, int bytes) {
 extern "C" int combat_trigger_fwd(const float *x, const void *noise, const float *P, const float *k1,
                                   float noise_rate, int32_t n, int32_t hw, float *out, void *out_c8,
                                   float *mse_partial, void *stream) {
-    if (!x || !noise || !P || !k1 || !out || n < 0 || hw < 16 || hw > 64) return COMBAT_EINVAL;
+    if (!x || !noise || !P || !k1 || !out || n < 0 || hw < 16 || hw > 64 || (hw & 3)) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    const int bytes = 7 * hw * hw * 4;
+    const int bytes = (4 * hw * hw + 2 * hw) * 4;
     if (set_smem(trigger_fwd_kernel, bytes)) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(trigger_fwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), x,
+    hipLaunchKernelGGL(trigger_fwd_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x,
                        reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, out,
-                       reinterpret_cast<uint4 *>(out_c8), mse_partial);
+                       reinterpret_cast<__bf16 *>(out_c8), mse_partial);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -305,14 +340,14 @@ extern "C" int combat_trigger_fwd(const float *x, const void *noise, const float
 extern "C" int combat_trigger_bwd(const float *x, const void *noise, const float *P, const float *k1,
                                   float noise_rate, int32_t n, int32_t hw, const float *d_out, const float *out,
                                   float l2_scale, int32_t pre_tanh, void *d_noise, void *stream) {
-    if (!x || !noise || !P || !k1 || !d_noise || n < 0 || hw < 16 || hw > 64) return COMBAT_EINVAL;
+    if (!x || !noise || !P || !k1 || !d_noise || n < 0 || hw < 16 || hw > 64 || (hw & 3)) return COMBAT_EINVAL;
     if (l2_scale != 0.f && !out) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    const int bytes = 8 * hw * hw * 4;
+    const int bytes = (5 * hw * hw + 2 * hw) * 4;
     if (set_smem(trigger_bwd_kernel, bytes)) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(trigger_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), x,
+    hipLaunchKernelGGL(trigger_bwd_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x,
                        reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, d_out, out, l2_scale,
-                       pre_tanh, reinterpret_cast<uint4 *>(d_noise));
+                       pre_tanh, reinterpret_cast<__bf16 *>(d_noise));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -342,12 +377,12 @@ extern "C" int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const f
 }
 
 extern "C" int combat_dct_u8(const float *x, const float *D, int32_t n, int32_t hw, void *out_c8, void *stream) {
-    if (!x || !D || !out_c8 || n < 0 || hw < 2 || hw > 64) return COMBAT_EINVAL;
+    if (!x || !D || !out_c8 || n < 0 || hw < 4 || hw > 64 || (hw & 3)) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    const int bytes = 7 * hw * hw * 4;
+    const int bytes = (4 * hw * hw + 2 * hw) * 4;
     if (set_smem(dct_u8_kernel, bytes)) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(dct_u8_kernel, dim3(n), dim3(256), bytes, as_stream(stream), x, D, hw,
-                       reinterpret_cast<uint4 *>(out_c8));
+    hipLaunchKernelGGL(dct_u8_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x, D, hw,
+                       reinterpret_cast<__bf16 *>(out_c8));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -249,13 +249,34 @@ class NetEngine:
         return pc
 
     def refresh(self) -> None:
-        """Re-derive bf16 operands (and folded eval-BN) after a parameter update."""
+        """Re-derive bf16 operands (and folded eval-BN) after a parameter update: one launch packs every
+        convolution of the network (device-side descriptor table, rebuilt if a weight tensor moved)."""
         if not self.weights_dirty:
             return
-        for pc in self.convs:
-            pc.pack()
+        self._pack_all()
         self._refresh_extra()
         self.weights_dirty = False
+
+    def _pack_all(self) -> None:
+        ptrs = tuple(pc.weight.data_ptr() for pc in self.convs)
+        if getattr(self, "_pack_ptrs", None) != ptrs:
+            masters = [pc.master() for pc in self.convs]
+            if any(m.data_ptr() != q for m, q in zip(masters, ptrs)):   # a weight is not channels_last: no stable view
+                self._pack_ptrs = None
+                for pc in self.convs:
+                    pc.pack()
+                return
+            from ._lib import PackDesc
+            tab = (PackDesc * len(self.convs))()
+            for d, pc, m in zip(tab, self.convs, masters):
+                d.w, d.wf, d.wd = m.data_ptr(), pc.wf.data_ptr(), (pc.wd.data_ptr() if pc.wd is not None else None)
+                d.K, d.taps, d.c_real, d.C, d.dup_hilo = pc.K, pc.taps, pc.c_real, pc.C, int(pc.dup_hilo)
+                d.rows_pad_f, d.kpad_f = pc.rows_f, pc.kpad_f
+                d.rows_pad_d, d.kpad_d = (pc.rows_d, pc.kpad_d) if pc.wd is not None else (0, 0)
+            self._pack_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+            self._pack_ptrs = ptrs
+        ops.check(lib.combat_pack_weights_batch(self._pack_tab.data_ptr(), len(self.convs),
+                                                torch.cuda.current_stream().cuda_stream), "combat_pack_weights_batch")
 
     def _refresh_extra(self) -> None:
         pass
@@ -396,13 +417,21 @@ class PreActEngine(NetEngine):
         self.lin_w, self.lin_b = m.linear.weight.data, m.linear.bias.data
 
     def _refresh_extra(self):
-        for bn in self.bns:
-            bn.fold()
+        self.fold_bn()
 
     def fold_bn(self):
-        """Running stats changed (a train-mode forward ran): refresh the folded eval scale/shift."""
-        for bn in self.bns:
-            bn.fold()
+        """Parameters or running stats changed: refresh every folded eval scale/shift (one launch)."""
+        ptrs = tuple(t.data_ptr() for bn in self.bns for t in (bn.gamma, bn.beta, bn.rm, bn.rv))
+        if getattr(self, "_bn_ptrs", None) != ptrs:
+            from ._lib import BnDesc
+            tab = (BnDesc * len(self.bns))()
+            for d, bn in zip(tab, self.bns):
+                d.gamma, d.beta, d.running_mean, d.running_var = (t.data_ptr() for t in (bn.gamma, bn.beta, bn.rm, bn.rv))
+                d.scale, d.shift, d.C = bn.escale.data_ptr(), bn.eshift.data_ptr(), bn.C
+            self._bn_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+            self._bn_ptrs = ptrs
+        ops.check(lib.combat_bn_eval_fold_batch(self._bn_tab.data_ptr(), len(self.bns), 1e-5,
+                                                torch.cuda.current_stream().cuda_stream), "combat_bn_eval_fold_batch")
 
     # ---- buffers of the head
     def head_bufs(self, slot: Slot):

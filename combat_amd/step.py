@@ -144,7 +144,7 @@ class AlternatedStep:
         self.cat_src = torch.zeros(2 * n, 3, hw, hw, dtype=f32, device=dev)   # [inputs ; poisoned images]
         self.bd = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)
         self.d_bd = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)
-        self.mse = torch.empty(n, dtype=f32, device=dev)
+        self.mse = torch.empty(3 * n, dtype=f32, device=dev)   # per (image, channel)
         # one host->device table per step: [5 aug tables | index_small | index_total | k1 x2]
         self.tab_f = torch.zeros(5, n, 4, dtype=f32, device=dev)
         self.tab_i = torch.zeros(2, n, dtype=torch.int32, device=dev)

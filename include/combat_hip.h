@@ -161,6 +161,15 @@ int combat_conv_wgrad(const combat_wgrad_args *a, void *stream);
 int combat_pack_weights(const float *w, int32_t K, int32_t taps, int32_t c_real, int32_t C, int32_t dup_hilo,
                         void *wf, int32_t rows_pad_f, int32_t kpad_f,
                         void *wd, int32_t rows_pad_d, int32_t kpad_d, void *stream);
+/* every convolution of a network in ONE launch (after each optimizer step all of them are stale):
+ * `descs` is an array of n descriptors in DEVICE memory, fields as the arguments above */
+typedef struct combat_pack_desc {
+    const float *w;
+    void *wf, *wd;
+    int32_t K, taps, c_real, C, dup_hilo, rows_pad_f, kpad_f, rows_pad_d, kpad_d;
+    int32_t reserved;
+} combat_pack_desc;
+int combat_pack_weights_batch(const combat_pack_desc *descs, int32_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Normalisation statistics (BatchNorm2d train: preact_resnet.py:20,22; InstanceNorm2d:
@@ -185,6 +194,13 @@ int64_t combat_norm_scratch_bytes(int32_t groups, int32_t C);
 int combat_bn_eval_fold(const float *gamma, const float *beta, const float *running_mean,
                         const float *running_var, float eps, int32_t C, float *scale, float *shift,
                         void *stream);
+/* all BatchNorm layers of a network in one launch; `descs`: n descriptors in DEVICE memory */
+typedef struct combat_bn_desc {
+    const float *gamma, *beta, *running_mean, *running_var;
+    float *scale, *shift;
+    int32_t C, reserved;
+} combat_bn_desc;
+int combat_bn_eval_fold_batch(const combat_bn_desc *descs, int32_t n, float eps, void *stream);
 
 /* column sums of x (and x*x) over runs of rows_per_group rows, for tensors whose normalisation
  * groups do not align with a conv tile granule (or whose producer is not a conv):
@@ -235,7 +251,7 @@ int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N, int32_t H,
  *   out = blur3x3(bd; k1[3] normalised 1-D kernel, reflect padding)
  * noise: bf16 NHWC c8 (channels 0..2) -- the generator's tanh output; x, out: fp32 NCHW [n][3][hw][hw].
  * out_c8 (may be NULL): the same result as the NHWC c8 hi/lo image the classifier stem reads.
- * mse_partial (may be NULL): fp32 [n] per-image sum (out - x)^2 (MSELoss, train_generator.py:234).
+ * mse_partial (may be NULL): fp32 [3n] per-(image, channel) sum (out - x)^2 (MSELoss, train_generator.py:234).
  * Backward: d_noise (bf16 NHWC c8) from d_out (fp32 NCHW) [+ 2*l2_scale*(out-x) MSE term];
  * pre_tanh != 0 multiplies by (1 - noise^2), i.e. returns the gradient w.r.t. the generator's
  * pre-tanh output (networks/models.py:340).

@@ -565,12 +565,12 @@ def test_trigger_forward_backward(ops, hw, sigma):
     k1 = dev(O.gaussian_kernel1d(sigma))
     out = torch.empty(n, 3, hw, hw, device="cuda")
     out8 = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
-    mse = torch.empty(n, device="cuda")
+    mse = torch.empty(3 * n, device="cuda")   # per (image, channel)
     ops.trigger_fwd(dev(x), n8, pm, k1, 0.08, out, out8, mse)
     nz = rb(noise).requires_grad_(True)
     ref = O.trigger_mix(x, nz, 0.08, 0.65, sigma)
     assert float((out.cpu() - ref).abs().max()) < 2e-5
-    assert rel_l2(mse, ((ref - x) ** 2).sum((1, 2, 3))) < 1e-4
+    assert rel_l2(mse.view(n, 3), ((ref - x) ** 2).sum((2, 3))) < 1e-4
     hi, lo = out8[..., :3].float().cpu(), out8[..., 3:6].float().cpu()
     assert float(((hi + lo).permute(0, 3, 1, 2) - ref).abs().max()) < 3e-5
     d_out = torch.randn(n, 3, hw, hw, generator=g(92))
