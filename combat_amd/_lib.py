@@ -45,6 +45,7 @@ class WgradArgs(C.Structure):
         ("src", c_vp), ("dy", c_vp), ("dw", c_vp), ("k_real", c_i32), ("c_real", c_i32),
         ("pro_scale", c_vp), ("pro_shift", c_vp), ("pro_group_stride", c_i32), ("pro_act", c_i32),
         ("pro_slope", c_f32), ("split", c_i32),
+        ("workspace", c_vp), ("workspace_bytes", c_i64),
     ]
 
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "combat_conv_stats_granule": (C.c_int, [C.c_int]),
     "combat_conv_stats_layout": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(c_i32), C.POINTER(c_i32)]),
     "combat_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
+    "combat_conv_wgrad_workspace_bytes": (c_i64, [C.POINTER(WgradArgs)]),
     "combat_pack_weights": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32,
                                       c_i32, c_vp]),
     "combat_norm_finalize": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -103,6 +105,7 @@ SIGNATURES = {
     "combat_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "combat_maxpool2": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_elu_affine": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "combat_affine_act": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
     "combat_dct_u8": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "combat_linear_nhwc": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
 }

@@ -13,6 +13,8 @@ int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *r
 int conv3x3d_launch(const combat_conv_args *a, int tile, hipStream_t st);
 // halo weight-gradient kernel (conv_wgrad3x3.hip): 0 launched, 1 not applicable, <0 error
 int conv_wgrad3x3_try(const combat_wgrad_args *a, hipStream_t st);
+int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st);   // same, for inputs without a prologue
+long conv_wgrad3x3_dma_workspace(const combat_wgrad_args *a);             // scratch bytes it can use (0: not applicable)
 
 template <int BM, int BN, int WGM_ = 0>
 struct TileCfg {

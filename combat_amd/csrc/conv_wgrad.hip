@@ -266,6 +266,10 @@ int launch(WgradParams p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int64_t combat_conv_wgrad_workspace_bytes(const combat_wgrad_args *a) {
+    return a && a->split >= 0 ? (int64_t)conv_wgrad3x3_dma_workspace(a) : 0;
+}
+
 extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
     if (!a || !a->src || !a->dy || !a->dw) return COMBAT_EINVAL;
     if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->P <= 0 || a->Q <= 0) return COMBAT_EINVAL;
@@ -283,7 +287,8 @@ extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
     p.ntaps = a->R * a->S;
     hipStream_t st = as_stream(stream);
     if (a->split >= 0) {   // split < 0 forces the generic kernel (tests)
-        const int rc = conv_wgrad3x3_try(a, st);
+        int rc = conv_wgrad3x3_dma_try(a, st);   // prologue-free input: both operands by LDS-DMA
+        if (rc == 1) rc = conv_wgrad3x3_try(a, st);
         if (rc <= 0) return rc;
     }
     if (a->split < 0) p.a.split = 0;

@@ -1,0 +1,408 @@
+// Weight gradient of a 3x3 / stride-1 / pad-1 convolution whose input needs NO prologue (it is already
+// the activated tensor), with both operands moved global -> LDS by the DMA path:
+//
+//   dW[n][tap][c] += sum_{pixels of this workgroup's tiles} dy[pix][n] * x[pix + tap][c]
+//
+// Same decomposition as conv_wgrad3x3.hip -- one workgroup owns a 64(n) x 64(c) tile of dW for all nine
+// taps and walks 64-pixel patches -- but a patch costs no VALU staging work: the dy tile and the
+// (TH+2) x (TW+2) halo patch of x are DMA'd (buffer_load ... lds, out-of-range offsets as the zero
+// padding) into a double-buffered stage while the MFMAs of the previous patch run; the only
+// synchronisation per patch is one s_waitcnt vmcnt(0) + s_barrier.  The register-staged kernel spent
+// ~600 VALU instructions per patch and thread on address arithmetic and the BatchNorm/ReLU prologue
+// against 72 MFMAs.
+//
+// LDS rows are 128 bytes (an LDS-DMA instruction writes 64 lanes x 16 B contiguously: no padding);
+// the four 32-byte channel pairs of a row sit at position (pair ^ key(row)), with key chosen per
+// geometry so that every ds_read_b64_tr_b16 (4 pixel rows x 32 B per 16 lanes, two groups of 8 rows per
+// 32 lanes) is bank-conflict-free.  Eight waves (two per SIMD, sharing one LDS stage): wave (wave_k,
+// wave_c) owns dst channels {16 wave_k + [0,16)} u {32 + 16 wave_k + [0,16)} -- its second dy fragment
+// is the first one's address ^ 64 -- and src channels 16 wave_c + [0,16), for all nine taps (72
+// accumulator registers).
+#include "conv_common.hpp"
+
+#ifndef COMBAT_EXPW
+#define COMBAT_EXPW 0
+#endif
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr unsigned kOob = 0x40000000u;
+
+struct W3dParams {
+    combat_wgrad_args a;
+    int TW, TH, TI, HWP, HH, HROWS, hpw, tw_shift, th_shift;
+    int tiles_x, tiles_y, ntiles, tiles_k, tiles_c, split, per;
+    unsigned x_bytes, dy_bytes;
+    float *ws;   // partial-sum slabs [split][tiles_k][tiles_c][9][64][64] or null (atomics)
+};
+
+__device__ __forceinline__ s16x4_t tr16d(const unsigned char *p) {
+#if COMBAT_EXPW == 1
+    return *reinterpret_cast<const s16x4_t *>(p);
+#endif
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t *)(reinterpret_cast<uintptr_t>(p)));
+}
+
+__device__ __forceinline__ bf16x8_t join8(const s16x4_t lo, const s16x4_t hi) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// position key of a halo row (line, column) / of a dy row (pixel index): see the file comment
+__device__ __forceinline__ int xkey(int TW, int line, int hx) {
+    return ((hx >> 1) & 1) | ((TW == 4 ? (line >> 1) & 1 : ((hx >> 3) + line) & 1) << 1);
+}
+__device__ __forceinline__ int dkey(int pk) { return ((pk >> 1) & 1) | (((pk >> 3) & 1) << 1); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// HPW = x halo pieces (8 rows each) per wave (compile time: the counted vmcnt waits need the DMA count
+// of a stage), NS = stages in the LDS ring (NS - 1 patches are in flight ahead of the one being consumed)
+template <int HPW, int NS>
+__device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const combat_wgrad_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_k = wid & 1, wave_c = wid >> 1;          // 2 x 4 waves over (n, c)
+    int bid = blockIdx.x;
+    const int tile_c = bid % p.tiles_c; bid /= p.tiles_c;
+    const int tile_k = bid % p.tiles_k;
+    const int sp = bid / p.tiles_k;
+    const int k0 = tile_k * 64, c0 = tile_c * 64;
+    const int t_begin = sp * p.per;
+    int t_end = t_begin + p.per;
+    if (t_end > p.ntiles) t_end = p.ntiles;
+    if (t_begin >= t_end) return;
+
+    const int C = a.C, K = a.K, H = a.H, W = a.W;
+    constexpr int stage_bytes = 64 * 128 + HPW * 8192;      // [dy tile | x halo patch]
+    constexpr int NDMA = 1 + HPW;                           // DMA instructions per wave and stage
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dyrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.dy), 0, p.dy_bytes, 0x00020000);
+
+    // ---- DMA bookkeeping that does not depend on the patch: this lane's row of every piece it issues
+    // (decoded position for the border tests, byte offset relative to the patch origin with the channel
+    // chunk its LDS slot must receive)
+    int hdec[HPW], hrel[HPW];   // x pieces: hx | hy << 8 | ti << 16, or -1 (row outside the halo patch)
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        const int row = (wid + 8 * j) * 8 + (lane >> 3), slot = lane & 7;
+        const int hx = row % p.HWP, line = row / p.HWP;
+        const int hy = line % p.HH, ti = line / p.HH;
+        const int chunk = (((slot >> 1) ^ xkey(p.TW, line, hx)) << 1) | (slot & 1);
+        hdec[j] = row < p.HROWS ? (hx | (hy << 8) | (ti << 16)) : -1;
+        hrel[j] = (((ti * H + hy - 1) * W + hx - 1) * C + c0 + chunk * 8) * 2;
+        asm volatile("" : "+v"(hdec[j]), "+v"(hrel[j]));
+    }
+    int dti[1], drel[1];        // dy piece: image of the patch, byte offset relative to the patch origin
+#pragma unroll
+    for (int j = 0; j < 1; ++j) {
+        const int pk = wid * 8 + (lane >> 3), slot = lane & 7;
+        const int tx = pk & (p.TW - 1), ty = (pk >> p.tw_shift) & (p.TH - 1), ti = pk >> (p.tw_shift + p.th_shift);
+        const int chunk = (((slot >> 1) ^ dkey(pk)) << 1) | (slot & 1);
+        dti[j] = ti;
+        drel[j] = (((ti * H + ty) * W + tx) * K + k0 + chunk * 8) * 2;
+        asm volatile("" : "+v"(dti[j]), "+v"(drel[j]));
+    }
+    auto issue = [&](int t, auto slot_tag) __attribute__((always_inline)) {
+        constexpr int sbase = decltype(slot_tag)::value * stage_bytes;
+        const int tx_ = t % p.tiles_x, ty_ = (t / p.tiles_x) % p.tiles_y, ig = t / (p.tiles_x * p.tiles_y);
+        const int img0 = ig * p.TI, oy0 = ty_ * p.TH, ox0 = tx_ * p.TW;
+        const int origin = (img0 * H + oy0) * W + ox0;        // wave-uniform
+        const int xorg = origin * C * 2, dorg = origin * K * 2;
+#pragma unroll
+        for (int j = 0; j < 1; ++j) {
+            const unsigned off = img0 + dti[j] < a.N ? (unsigned)(dorg + drel[j]) : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyrsrc, (lds_void_t *)(smem + sbase + wid * 1024), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) {
+            const int d = hdec[j];
+            const bool ok = d >= 0 && img0 + (d >> 16) < a.N && (unsigned)(oy0 + ((d >> 8) & 255) - 1) < (unsigned)H &&
+                            (unsigned)(ox0 + (d & 255) - 1) < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(xorg + hrel[j]) : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void_t *)(smem + sbase + 8192 + (wid + 8 * j) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+
+    // ---- per-lane fragment addresses (relative to the stage).  Transposing read: lane 4q+pp of a
+    // 16-lane group addresses pixel row q (4 rows per read), channels 4pp..4pp+3 of the fragment's 16,
+    // and receives the 4 pixels of channel (lane & 15).
+    const int q = (lane & 15) >> 2, pp = lane & 3, fq = lane >> 4;
+    int dya[2][2], xa[2][2][9];                             // [k-step][lo/hi 4-pixel group]([tap]); dy fragment 1 = ^ 64
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int pk = ks * 32 + fq * 8 + q + 4 * hi;   // pixel of the 64-pixel tile
+            dya[ks][hi] = pk * 128 + ((wave_k ^ dkey(pk)) & 3) * 32 + pp * 8;
+            const int tx = pk & (p.TW - 1), ty = (pk >> p.tw_shift) & (p.TH - 1), ti = pk >> (p.tw_shift + p.th_shift);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int r = (tap * 11) >> 5, s = tap - 3 * r;
+                const int line = ti * p.HH + ty + r, hx = tx + s;
+                xa[ks][hi][tap] = 8192 + (line * p.HWP + hx) * 128 + ((wave_c ^ xkey(p.TW, line, hx)) & 3) * 32 + pp * 8;
+                // pin the value: left alone the compiler re-derives all 36 addresses inside the patch loop
+                // (~460 VALU instructions per patch) instead of keeping them in registers
+                asm volatile("" : "+v"(xa[ks][hi][tap]));
+            }
+            asm volatile("" : "+v"(dya[ks][hi]));
+        }
+
+    f32x4_t acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- MFMAs of one staged patch: 9 taps x 2 k-steps x 2 dy fragments.  The dy fragments of both
+    // k-steps are read once per patch; the x fragments of tap t+1 are in flight while tap t's MFMAs run.
+    auto x_frags = [&](bf16x8_t (&fx)[2], const unsigned char *st, auto tap_tag) __attribute__((always_inline)) {   // st: compile-time stage base
+        constexpr int tap = decltype(tap_tag)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fx[ks] = join8(tr16d(st + xa[ks][0][tap]), tr16d(st + xa[ks][1][tap]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_tap = [&](auto tap_tag, const bf16x8_t (&fk)[2][2], const bf16x8_t (&fx)[2]) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tap_tag)::value;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[tap][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[ks][i], fx[ks], acc[tap][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](auto slot_tag) __attribute__((always_inline)) {
+        const unsigned char *st = smem + decltype(slot_tag)::value * stage_bytes;   // folds into the reads' immediates
+        bf16x8_t fk[2][2], fx0[2], fx1[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                fk[ks][i] = join8(tr16d(st + (dya[ks][0] ^ (i * 64))), tr16d(st + (dya[ks][1] ^ (i * 64))));
+        using std::integral_constant;
+        x_frags(fx0, st, integral_constant<int, 0>{});
+#define COMBAT_W3_TAP(t, cur, nxt)                                                   \
+        if (t < 8) x_frags(nxt, st, integral_constant<int, (t < 8 ? t + 1 : 8)>{});  \
+        mfma_tap(integral_constant<int, t>{}, fk, cur);
+        COMBAT_W3_TAP(0, fx0, fx1) COMBAT_W3_TAP(1, fx1, fx0) COMBAT_W3_TAP(2, fx0, fx1) COMBAT_W3_TAP(3, fx1, fx0)
+        COMBAT_W3_TAP(4, fx0, fx1) COMBAT_W3_TAP(5, fx1, fx0) COMBAT_W3_TAP(6, fx0, fx1) COMBAT_W3_TAP(7, fx1, fx0)
+        COMBAT_W3_TAP(8, fx0, fx1)
+#undef COMBAT_W3_TAP
+    };
+
+    // ---- ring of NS stages: patch i of this workgroup lives in slot i % NS; NS - 1 patches are DMA'd
+    // ahead.  The loop is unrolled over the slots so that every LDS address is "register + immediate".
+    // At the top of iteration i every wave has passed the barrier that followed compute(i - 1), so
+    // slot (i - 1) % NS is free for patch i + NS - 1.  The wait after compute(i) needs patch i + 1 only:
+    // everything younger (NS - 2 patches) may stay in flight.
+    const int npatch = t_end - t_begin;
+    using std::integral_constant;
+    issue(t_begin, integral_constant<int, 0>{});
+    if (NS > 2 && npatch > 1) issue(t_begin + 1, integral_constant<int, 1 % NS>{});
+    if (NS > 2 && npatch > 1) wait_vm_lgkm0_barrier<NDMA>(); else wait_vm_lgkm0_barrier<0>();
+    auto body = [&](auto slot_tag, int i) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slot_tag)::value, nslot = (slot + NS - 1) % NS;
+        const bool ahead = i + NS - 1 < npatch;
+        if (ahead) issue(t_begin + i + NS - 1, integral_constant<int, nslot>{});
+        compute(integral_constant<int, slot>{});
+        if (ahead) wait_vm_lgkm0_barrier<(NS - 2) * NDMA>(); else wait_vm_lgkm0_barrier<0>();
+    };
+    for (int i = 0; i < npatch; i += NS) {
+        body(integral_constant<int, 0>{}, i);
+        if (NS > 1 && i + 1 < npatch) body(integral_constant<int, 1 % NS>{}, i + 1);
+        if (NS > 2 && i + 2 < npatch) body(integral_constant<int, 2 % NS>{}, i + 2);
+    }
+    static_assert(NS == 2 || NS == 3, "the patch loop is unrolled for rings of two or three stages");
+
+    // ---- nine [64 n][64 c] partials -> fp32 LDS image -> atomics in 256-byte runs along c
+    float *ep = reinterpret_cast<float *>(smem);
+    constexpr int EPS = 68;
+    const int fr = lane & 15;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int col = wave_c * 16 + fr;
+            const int row = (i * 2 + wave_k) * 16 + fq * 4;
+            f32x4_t v;
+            switch (tap) {   // acc is indexed statically (a runtime index would put it in scratch)
+                case 0: v = acc[0][i]; break;
+                case 1: v = acc[1][i]; break;
+                case 2: v = acc[2][i]; break;
+                case 3: v = acc[3][i]; break;
+                case 4: v = acc[4][i]; break;
+                case 5: v = acc[5][i]; break;
+                case 6: v = acc[6][i]; break;
+                case 7: v = acc[7][i]; break;
+                default: v = acc[8][i]; break;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ep[(row + e) * EPS + col] = v[e];
+        }
+        __syncthreads();
+        if (p.ws) {   // this workgroup's slab: plain 16-byte stores, combined by wgrad3x3_reduce_kernel
+            float *slab = p.ws + ((size_t)blockIdx.x * 9 + tap) * 4096;
+            for (int idx = tid; idx < 64 * 16; idx += 512) {
+                const int row = idx >> 4, c4 = (idx & 15) * 4;
+                const float *e = ep + row * EPS + c4;
+                *reinterpret_cast<f32x4_t *>(slab + row * 64 + c4) = f32x4_t{e[0], e[1], e[2], e[3]};
+            }
+        } else {
+            for (int idx = tid; idx < 64 * 64; idx += 512) {
+                const int row = idx >> 6, col = idx & 63;
+                const int n = k0 + row, c = c0 + col;
+                if (n < a.k_real && c < a.c_real) atomicAdd(a.dw + ((size_t)n * 9 + tap) * a.c_real + c, ep[row * EPS + col]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dw += sum over the pixel ranges' slabs.  grid.x: 4-element groups of the [tiles][9][64][64] partial
+// tile space (256 threads each), grid.y: groups of ranges (each adds its share with one fp32 atomic
+// per element -- a few per element instead of `split`).
+__global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw,
+                                                              int base, int tiles_c, int split, int k_real, int c_real) {
+    const long e4 = (long)blockIdx.x * 256 + threadIdx.x;          // float4 index inside [base][9][64][16]
+    if (e4 >= (long)base * 9 * 1024) return;
+    const int c4 = (int)(e4 & 15) * 4, row = (int)(e4 >> 4) & 63, tap = (int)((e4 >> 10) % 9), tile = (int)(e4 / (9 * 1024));
+    const int per = (split + gridDim.y - 1) / gridDim.y;
+    const int s0 = blockIdx.y * per, s1 = s0 + per < split ? s0 + per : split;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const float *src = ws + ((size_t)tile * 9 + tap) * 4096 + row * 64 + c4;
+    const size_t sstride = (size_t)base * 9 * 4096;
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {   // four independent loads in flight
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t *>(src + (size_t)s * sstride);
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t *>(src + (size_t)(s + 1) * sstride);
+        const f32x4_t v2 = *reinterpret_cast<const f32x4_t *>(src + (size_t)(s + 2) * sstride);
+        const f32x4_t v3 = *reinterpret_cast<const f32x4_t *>(src + (size_t)(s + 3) * sstride);
+        acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; s < s1; ++s) acc += *reinterpret_cast<const f32x4_t *>(src + (size_t)s * sstride);
+    const int tile_c = tile % tiles_c, tile_k = tile / tiles_c;
+    const int n = tile_k * 64 + row, c = tile_c * 64 + c4;
+    if (n < k_real && s0 < s1) {
+        float *o = dw + ((size_t)n * 9 + tap) * c_real + c;
+        if (gridDim.y == 1 && c + 3 < c_real) {   // sole owner of these elements: no atomics
+            *reinterpret_cast<f32x4_t *>(o) += acc;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < c_real) atomicAdd(o + e, acc[e]);
+        }
+    }
+}
+
+// (the body is a device function: the host pass cannot see the buffer-resource type it uses)
+template <int HPW, int NS>
+__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_dma_kernel(const W3dParams p) { wgrad3x3_dma_body<HPW, NS>(p); }
+
+template <int HPW, int NS>
+int launch_w3d(const W3dParams &p, int blocks, hipStream_t st) {
+    constexpr int stage = 8192 + HPW * 8192;
+    constexpr int ep = 64 * 68 * 4;
+    constexpr int smem = NS * stage > ep ? NS * stage : ep;
+    auto kern = conv_wgrad3x3_dma_kernel<HPW, NS>;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, st, p);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+bool w3d_geometry(const combat_wgrad_args *a, W3dParams &p, int &smem) {
+    if (!(a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->P == a->H && a->Q == a->W)) return false;
+    if (a->pro_scale || a->pro_act) return false;   // operands go straight to LDS
+    if (a->C < 64 || (a->C & 63) || a->K < 64 || (a->K & 63) || a->c_real != a->C) return false;
+    const int W = a->W, H = a->H;
+    const int TW = W < 16 ? W : 16;
+    const int TH = H < 64 / TW ? H : 64 / TW;
+    const int TI = 64 / (TW * TH);
+    if (TW < 2 || TI < 1 || TW * TH * TI != 64) return false;
+    p.a = *a;
+    p.TW = TW; p.TH = TH; p.TI = TI;
+    p.HWP = TW + 2; p.HH = TH + 2; p.HROWS = TI * p.HH * p.HWP;
+    p.hpw = (p.HROWS + 63) / 64;   // 8-row pieces per wave, eight waves
+    p.tw_shift = ilog2_exact(TW); p.th_shift = ilog2_exact(TH);
+    if (p.tw_shift < 0 || p.th_shift < 0 || W % TW || H % TH) return false;
+    const long xb = (long)a->N * H * W * a->C * 2, db = (long)a->N * H * W * a->K * 2;
+    if (xb >= (long)kOob || db >= (long)kOob) return false;
+    p.x_bytes = (unsigned)xb; p.dy_bytes = (unsigned)db;
+    p.tiles_x = W / TW; p.tiles_y = H / TH;
+    p.ntiles = p.tiles_x * p.tiles_y * ((a->N + TI - 1) / TI);
+    p.tiles_k = a->K / 64; p.tiles_c = a->C / 64;
+    smem = 0;
+    return p.hpw >= 2 && p.hpw <= 4;
+}
+
+// number of pixel ranges: one workgroup per (tile, range), one workgroup per CU, >= 4 patches each.
+// With a workspace the partial sums cost plain stores; without, fp32 atomics (147 KB per workgroup)
+// against a ~24 MB budget.
+int pick_split(const combat_wgrad_args *a, const W3dParams &p, bool with_ws) {
+    const int base = p.tiles_k * p.tiles_c;
+    int split = a->split;
+    if (split <= 0) {
+        const int by_cus = (256 + base - 1) / base;
+        const int by_atomics = 164 / base > 0 ? 164 / base : 1;
+        split = with_ws || by_cus < by_atomics ? by_cus : by_atomics;
+        const int by_work = (p.ntiles + 3) / 4;
+        if (split > by_work) split = by_work;
+        if (split < 1) split = 1;
+    }
+    if (split > p.ntiles) split = p.ntiles;
+    const int per = (p.ntiles + split - 1) / split;
+    return (p.ntiles + per - 1) / per;
+}
+
+}  // namespace
+
+long conv_wgrad3x3_dma_workspace(const combat_wgrad_args *a) {
+    W3dParams p;
+    int smem;
+    if (!w3d_geometry(a, p, smem)) return 0;
+    const int split = pick_split(a, p, true);
+    return split > 1 ? (long)split * p.tiles_k * p.tiles_c * 9 * 4096 * 4 : 0;
+}
+
+// returns COMBAT_OK if launched, 1 if this kernel does not apply (caller falls back), <0 on error
+int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st) {
+    W3dParams p;
+    int smem;
+    if (!w3d_geometry(a, p, smem)) return 1;
+    const int base = p.tiles_k * p.tiles_c;
+    int split = pick_split(a, p, true);
+    const bool use_ws = split > 1 && a->workspace && a->workspace_bytes >= (long)split * base * 9 * 4096 * 4;
+    if (!use_ws) split = pick_split(a, p, false);
+    p.ws = use_ws ? reinterpret_cast<float *>(a->workspace) : nullptr;
+    p.per = (p.ntiles + split - 1) / split;
+    p.split = (p.ntiles + p.per - 1) / p.per;
+    const int blocks = base * p.split;
+    int rc;
+    if (p.hpw == 2) rc = launch_w3d<2, 3>(p, blocks, st);        // 3 x 24 KB
+    else if (p.hpw == 3) rc = launch_w3d<3, 2>(p, blocks, st);   // 2 x 32 KB (ds_read immediates reach 64 KB)
+    else rc = launch_w3d<4, 2>(p, blocks, st);                   // 2 x 40 KB
+    if (rc != COMBAT_OK || !p.ws) return rc;
+    // enough workgroups to fill the chip; each group of ranges costs one fp32 atomic per element
+    const long e4 = (long)base * 9 * 1024;
+    int groups = (int)(512 / ((e4 + 255) / 256));
+    if (groups < 1) groups = 1;
+    if (groups > p.split) groups = p.split;
+    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3((unsigned)((e4 + 255) / 256), groups), dim3(256), 0, st, p.ws, a->dw, base,
+                       p.tiles_c, p.split, a->k_real, a->c_real);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}

@@ -36,35 +36,46 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
     }
 }
 
-// every convolution of a network: blockIdx.y = descriptor
+// every convolution of a network: blockIdx.y = descriptor.  The forward layout keeps the master's
+// channel order (coalesced both ways); the input-gradient layout swaps the roles of dst channel and
+// src channel, so it goes through 32 x 32 LDS tiles: 128-byte reads along c, 64-byte writes along n.
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const combat_pack_desc *__restrict__ descs) {
+    __shared__ float tile[32][33];
     const combat_pack_desc d = descs[blockIdx.y];
     const float *__restrict__ w = d.w;
     __bf16 *__restrict__ wf = reinterpret_cast<__bf16 *>(d.wf);
     __bf16 *__restrict__ wd = reinterpret_cast<__bf16 *>(d.wd);
     const int K = d.K, taps = d.taps, creal = d.c_real, C = d.C, Kc = (d.K + 7) & ~7;
     const long nf = (long)d.rows_pad_f * d.kpad_f;
-    const long nd = wd ? (long)d.rows_pad_d * d.kpad_d : 0;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nf + nd; t += (long)gridDim.x * blockDim.x) {
-        if (t < nf) {
-            const int n = (int)(t / d.kpad_f), k = (int)(t - (long)n * d.kpad_f);
-            const int tap = k / C, c = k - tap * C;
-            float v = 0.f;
-            if (n < K && tap < taps) {
-                int cm = -1;
-                if (c < creal) cm = c;
-                else if (d.dup_hilo && c < 2 * creal) cm = c - creal;
-                if (cm >= 0) v = w[((long)n * taps + tap) * creal + cm];
-            }
-            wf[t] = (__bf16)v;
-        } else {
-            const long u = t - nf;
-            const int c = (int)(u / d.kpad_d), k = (int)(u - (long)c * d.kpad_d);
-            const int tap = k / Kc, n = k - tap * Kc;
-            float v = 0.f;
-            if (c < creal && tap < taps && n < K) v = w[((long)n * taps + tap) * creal + c];
-            wd[u] = (__bf16)v;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nf; t += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(t / d.kpad_f), k = (int)(t - (long)n * d.kpad_f);
+        const int tap = k / C, c = k - tap * C;
+        float v = 0.f;
+        if (n < K && tap < taps) {
+            int cm = -1;
+            if (c < creal) cm = c;
+            else if (d.dup_hilo && c < 2 * creal) cm = c - creal;
+            if (cm >= 0) v = w[((long)n * taps + tap) * creal + cm];
         }
+        wf[t] = (__bf16)v;
+    }
+    if (!wd) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tiles_k = d.kpad_d / 32, tiles_c = (d.rows_pad_d + 31) / 32;   // kpad is a multiple of 64
+    for (int tl = blockIdx.x; tl < tiles_k * tiles_c; tl += gridDim.x) {
+        const int c0 = (tl / tiles_k) * 32, k0 = (tl % tiles_k) * 32;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int kl = ty + 8 * it, k = k0 + kl, tap = k / Kc, n = k - tap * Kc, c = c0 + tx;
+            tile[kl][tx] = (c < creal && tap < taps && n < K) ? w[((long)n * taps + tap) * creal + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int cl = ty + 8 * it, c = c0 + cl;
+            if (c < d.rows_pad_d) wd[(long)c * d.kpad_d + k0 + tx] = (__bf16)tile[tx][cl];
+        }
+        __syncthreads();
     }
 }
 
@@ -184,6 +195,33 @@ __global__ __launch_bounds__(256) void elu_affine_kernel(const __bf16 *__restric
             const float el = v[e] > 0.f ? v[e] : expm1f(v[e]);
             v[e] = fmaf(el, sc[e], sh[e]);
         }
+        *reinterpret_cast<uint4 *>(out + t * 8) = pack8(v);
+    }
+}
+
+// out = lrelu(x * scale[g][c] + shift[g][c], slope), g = row / group_rows (group_rows 0: one group):
+// the activation a train-mode convolution's prologue would compute, as a tensor (same fma, same rounding)
+__global__ __launch_bounds__(256) void affine_act_kernel(const __bf16 *__restrict__ x, long rows, int C,
+                                                         const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, long group_rows,
+                                                         float slope, __bf16 *__restrict__ out) {
+    const int nch = C >> 3;
+    const long total = rows * nch;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long row = t / nch;
+        const int c = (int)(t - row * nch) * 8;
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4 *>(x + t * 8), v);
+        if (scale) {
+            const long g = group_rows > 0 ? (row / group_rows) * C : 0;
+            float sc[8], sh[8];
+            load8f(scale + g + c, sc);
+            load8f(shift + g + c, sh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
         *reinterpret_cast<uint4 *>(out + t * 8) = pack8(v);
     }
 }
@@ -373,7 +411,7 @@ extern "C" int combat_pack_weights(const float *w, int32_t K, int32_t taps, int3
 extern "C" int combat_pack_weights_batch(const combat_pack_desc *descs, int32_t n, void *stream) {
     if (!descs || n < 0) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(96, (unsigned)n), dim3(256), 0, as_stream(stream), descs);
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(128, (unsigned)n), dim3(256), 0, as_stream(stream), descs);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -439,6 +477,17 @@ extern "C" int combat_elu_affine(const void *x, int64_t rows, int32_t C, const f
     if (!x || !out || !scale || !shift || rows <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     hipLaunchKernelGGL(elu_affine_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), (long)rows, C, scale, shift,
+                       reinterpret_cast<__bf16 *>(out));
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_affine_act(const void *x, int64_t rows, int32_t C, const float *scale, const float *shift,
+                                 int64_t group_rows, float slope, void *out, void *stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || group_rows < 0) return COMBAT_EINVAL;
+    if ((scale == nullptr) != (shift == nullptr)) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(rows * (C / 8), 8192)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const __bf16 *>(x), (long)rows, C, scale, shift, (long)group_rows, slope,
                        reinterpret_cast<__bf16 *>(out));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;

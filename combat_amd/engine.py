@@ -206,8 +206,35 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
         a.pro_scale, a.pro_shift = _p(pro.scale), _p(pro.shift)
         a.pro_group_stride, a.pro_act, a.pro_slope = pro.group_stride, int(pro.act), pro.slope
     a.split = 0
-    plan.hold(a, src, dy, dw, pro)
+    ws = _wgrad_workspace(src.device)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    plan.hold(a, src, dy, dw, pro, ws)
     plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a))
+
+
+_WGRAD_WS: Dict = {}
+
+
+def _wgrad_workspace(device) -> torch.Tensor:
+    """One scratch buffer per device for the weight-gradient partial sums (launches on a stream run one
+    after the other): pixel ranges x tiles <= ~256 + tiles slabs of 147 KB.  A launch that would need more
+    falls back to fp32 atomics by itself."""
+    ws = _WGRAD_WS.get(device)
+    if ws is None:
+        ws = torch.empty(48 << 20, dtype=torch.uint8, device=device)
+        _WGRAD_WS[device] = ws
+    return ws
+
+
+def rec_act(plan: Plan, what: str, src, dst, aff: Affine):
+    """dst = lrelu(src * scale + shift) as a tensor (what a convolution prologue with `aff` computes)."""
+    c = src.shape[-1]
+    rows = src.numel() // c
+    group_rows = (src.shape[1] * src.shape[2]) if aff.group_stride else 0
+    assert aff.act and aff.group_stride in (0, c)
+    plan.hold(src, dst, aff)
+    plan.add(what, lib.combat_affine_act, src.data_ptr(), rows, c, _p(aff.scale), _p(aff.shift), group_rows,
+             float(aff.slope), dst.data_ptr())
 
 
 def _pow2_part(pq: int, cap: int = 32) -> int:
@@ -493,8 +520,10 @@ class PreActEngine(NetEngine):
         return P
 
     def _forward_train_body(self, P: Plan, slot: Slot, x):
-        """Train mode: BatchNorm uses batch statistics, produced by the epilogue of the convolution
-        that writes the normalised tensor and consumed as the prologue of the next one."""
+        """Train mode: BatchNorm uses batch statistics, produced by the epilogue of the convolution that
+        writes the normalised tensor.  relu(bn(.)) is then materialised once per BatchNorm ('b%d.a0' =
+        block input through bn1, 'b%d.a1t' = conv1 output through bn2): the forward convolutions and
+        the weight-gradient passes that read it need no prologue and take their operands by LDS-DMA."""
         n, hw = slot.N, slot.hw
         cur = slot.buf("stem", (n, hw, hw, 64))
         first = self.blocks[0].bn1
@@ -504,23 +533,26 @@ class PreActEngine(NetEngine):
         chw = hw
         for b, blk in enumerate(self.blocks):
             ohw = chw // blk.stride
+            a0 = slot.buf("b%d.a0" % b, cur.shape)
+            rec_act(P, "b%d.act0" % b, cur, a0, aff)
             if blk.sc is not None:
                 resid = slot.buf("b%d.sc" % b, (n, ohw, ohw, blk.planes))
-                rec_conv(P, "b%d.sc" % b, cur, resid, blk.sc, 0, pro=aff)
+                rec_conv(P, "b%d.sc" % b, a0, resid, blk.sc, 0)
             else:
                 resid = cur
             y1 = slot.buf("b%d.y1" % b, (n, ohw, ohw, blk.planes))
             out = slot.buf("b%d.out" % b, (n, ohw, ohw, blk.planes))
             nxt = self.blocks[b + 1].bn1 if b + 1 < len(self.blocks) else None
-            st2 = self._conv_norm(P, slot, blk.bn2.prefix, cur, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
-                                  beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt), pro=aff)
-            aff2 = Affine(st2.scale, st2.shift, 0, True, 0.0)
+            st2 = self._conv_norm(P, slot, blk.bn2.prefix, a0, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
+                                  beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt))
+            a1 = slot.buf("b%d.a1t" % b, y1.shape)
+            rec_act(P, "b%d.act1" % b, y1, a1, Affine(st2.scale, st2.shift, 0, True, 0.0))
             if nxt is not None:
-                st = self._conv_norm(P, slot, nxt.prefix, y1, out, blk.conv2, groups=1, gamma=nxt.gamma,
-                                     beta=nxt.beta, running=(nxt.rm, nxt.rv, nxt.nbt), pro=aff2, add_post=resid)
+                st = self._conv_norm(P, slot, nxt.prefix, a1, out, blk.conv2, groups=1, gamma=nxt.gamma,
+                                     beta=nxt.beta, running=(nxt.rm, nxt.rv, nxt.nbt), add_post=resid)
                 aff = Affine(st.scale, st.shift, 0, True, 0.0)
             else:
-                rec_conv(P, "b%d.c2" % b, y1, out, blk.conv2, 0, pro=aff2, add_post=resid)
+                rec_conv(P, "b%d.c2" % b, a1, out, blk.conv2, 0, add_post=resid)
             cur, chw = out, ohw
         return cur, chw
 
@@ -583,10 +615,9 @@ class PreActEngine(NetEngine):
             blk = self.blocks[b]
             xin, y1, _ = self._block_io(slot, b)
             st1, st2 = slot.norm[blk.bn1.prefix], slot.norm[blk.bn2.prefix]
-            aff1 = Affine(st1.scale, st1.shift, 0, True, 0.0)
-            aff2 = Affine(st2.scale, st2.shift, 0, True, 0.0)
+            a0, a1 = slot.bufs["b%d.a0" % b], slot.bufs["b%d.a1t" % b]   # relu(bn1(xin)), relu(bn2(y1)) of the forward
             pre = blk.prefix
-            rec_wgrad(P, "b%d.c2.wgrad" % b, y1, d_out, blk.conv2, fp.grad_phys(pre + "conv2.weight"), aff2)
+            rec_wgrad(P, "b%d.c2.wgrad" % b, a1, d_out, blk.conv2, fp.grad_phys(pre + "conv2.weight"))
             dz2 = slot.buf("g.b%d.dz2" % b, y1.shape)
             self._dgrad_norm(P, slot, "g." + blk.bn2.prefix, d_out, dz2, blk.conv2, y1, st2, group_stride=0,
                              slope=0.0, gamma=blk.bn2.gamma, dgamma=fp.grad_phys(pre + "bn2.weight"),
@@ -595,10 +626,10 @@ class PreActEngine(NetEngine):
             self._bwd_apply(P, "g." + blk.bn2.prefix, dz2, y1, dy1, st2)
             tsc = None
             if blk.sc is not None:
-                rec_wgrad(P, "b%d.sc.wgrad" % b, xin, d_out, blk.sc, fp.grad_phys(pre + "shortcut.0.weight"), aff1)
+                rec_wgrad(P, "b%d.sc.wgrad" % b, a0, d_out, blk.sc, fp.grad_phys(pre + "shortcut.0.weight"))
                 tsc = slot.buf("g.b%d.tsc" % b, xin.shape)
                 rec_conv(P, "b%d.sc.dgrad" % b, d_out, tsc, blk.sc, 1)
-            rec_wgrad(P, "b%d.c1.wgrad" % b, xin, dy1, blk.conv1, fp.grad_phys(pre + "conv1.weight"), aff1)
+            rec_wgrad(P, "b%d.c1.wgrad" % b, a0, dy1, blk.conv1, fp.grad_phys(pre + "conv1.weight"))
             dz1 = slot.buf("g.b%d.dz1" % b, xin.shape)
             self._dgrad_norm(P, slot, "g." + blk.bn1.prefix, dy1, dz1, blk.conv1, xin, st1, group_stride=0,
                              slope=0.0, gamma=blk.bn1.gamma, dgamma=fp.grad_phys(pre + "bn1.weight"),
@@ -708,7 +739,11 @@ class UnetEngine(NetEngine):
             # IN(conv(x) + b) == IN(conv(x)) exactly, and leaving b out keeps the stored bf16
             # tensor better centred (less rounding error amplified by 1/sigma)
             dst = T(name, s, c)
-            st = self._conv_norm(P, slot, name, src, dst, pc[name], groups=n, pro=pro)
+            if pro is not None:   # materialise the activated input once ('a.<conv>'): forward and wgrad then need no prologue
+                act = slot.buf("a." + name, src.shape)
+                rec_act(P, name + ".act", src, act, pro)
+                src = act
+            st = self._conv_norm(P, slot, name, src, dst, pc[name], groups=n)
             return dst, st
 
         t01, s01 = cn("conv0_1", t00, h1, nf, lr_only)
@@ -764,7 +799,11 @@ class UnetEngine(NetEngine):
             """dy = gradient w.r.t. raw output of conv `pcv` whose input is LR(IN(t[src_name])).
             wgrad of pcv, then gradient w.r.t. t[src_name] (returned)."""
             src, st = t(src_name), stn(src_name)
-            rec_wgrad(P, name + ".wgrad", src, dy, pcv, fp.grad_phys(name + ".weight"), self._in_aff(st))
+            act = slot.bufs.get("a." + name)   # LR(IN(src)) of the forward (all but the K = 8 output layer)
+            if act is not None:
+                rec_wgrad(P, name + ".wgrad", act, dy, pcv, fp.grad_phys(name + ".weight"))
+            else:
+                rec_wgrad(P, name + ".wgrad", src, dy, pcv, fp.grad_phys(name + ".weight"), self._in_aff(st))
             dz = G(src_name + ".dz", src)
             self._dgrad_norm(P, slot, "g." + src_name, dy, dz, pcv, src, st, group_stride=st.C, slope=self.LR,
                              add_pre=add_pre)
@@ -807,7 +846,7 @@ class UnetEngine(NetEngine):
         # conv0_1 reads LeakyReLU(conv0_0 output): no norm in between
         t00 = t("conv0_0")
         lr_only = Affine(None, None, 0, True, self.LR)
-        rec_wgrad(P, "conv0_1.wgrad", t00, d, pc["conv0_1"], fp.grad_phys("conv0_1.weight"), lr_only)
+        rec_wgrad(P, "conv0_1.wgrad", slot.bufs["a.conv0_1"], d, pc["conv0_1"], fp.grad_phys("conv0_1.weight"))
         d00 = G("conv0_0.dx", t00)
         rec_conv(P, "conv0_1.dgrad", d, d00, pc["conv0_1"], 1, mask_x=t00, mask=Affine(None, None, 0, True, self.LR))
         P.add("db.conv0_0", lib.combat_colsum, d00.data_ptr(), d00.numel() // d00.shape[-1], d00.shape[-1],

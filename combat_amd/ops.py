@@ -146,8 +146,9 @@ def conv_launch(a: ConvArgs) -> None:
                                                                    a.stride))
 
 
-def conv_wgrad(src, dy, pc: PackedConv, dw, *, pro: Optional[Affine] = None, split=0) -> None:
-    """dw (fp32 [K][taps][c_real], pre-zeroed) += wgrad."""
+def conv_wgrad(src, dy, pc: PackedConv, dw, *, pro: Optional[Affine] = None, split=0, workspace=None) -> None:
+    """dw (fp32 [K][taps][c_real], pre-zeroed) += wgrad.  workspace=True allocates the scratch the launch
+    can use (partial sums by plain stores + one reduction instead of fp32 atomics); a tensor is used as is."""
     a = WgradArgs()
     a.N, a.H, a.W, a.C = src.shape
     _, a.P, a.Q, a.K = dy.shape
@@ -158,6 +159,11 @@ def conv_wgrad(src, dy, pc: PackedConv, dw, *, pro: Optional[Affine] = None, spl
         a.pro_scale, a.pro_shift = _p(pro.scale), _p(pro.shift)
         a.pro_group_stride, a.pro_act, a.pro_slope = pro.group_stride, int(pro.act), pro.slope
     a.split = split
+    if workspace is True:
+        nbytes = int(lib.combat_conv_wgrad_workspace_bytes(ctypes.byref(a)))
+        workspace = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=src.device) if nbytes else None
+    if workspace is not None:
+        a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     check(lib.combat_conv_wgrad(ctypes.byref(a), _stream()), "combat_conv_wgrad",
           "src=%s dy=%s" % (tuple(src.shape), tuple(dy.shape)))
 

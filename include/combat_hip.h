@@ -150,9 +150,16 @@ typedef struct combat_wgrad_args {
     int32_t split;               /* number of pixel ranges: 0 = auto, > 0 explicit, < 0 = auto with the
                                     generic per-tap kernel forced (3x3/s1 layers otherwise use the
                                     LDS-patch kernel that computes all nine taps per workgroup) */
+    void *workspace;             /* optional scratch (may be NULL): with at least
+                                    combat_conv_wgrad_workspace_bytes(a) bytes the pixel ranges' partial
+                                    sums are combined by plain stores + one reduction launch instead
+                                    of fp32 atomics (the chip sustains ~1.3 TB/s of those) */
+    int64_t workspace_bytes;
 } combat_wgrad_args;
 
 int combat_conv_wgrad(const combat_wgrad_args *a, void *stream);
+/* scratch bytes the launch for these args can use (0: none) */
+int64_t combat_conv_wgrad_workspace_bytes(const combat_wgrad_args *a);
 
 /* fp32 [K][taps][c_real] master weights -> bf16 packed operands.
  * wf: forward  [rows_pad(K)][kpad_f], k = tap*C + c   (C = padded channel count, hi/lo dup if dup_hilo)
@@ -325,6 +332,13 @@ int combat_maxpool2(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, v
 /* y = BN_eval(ELU(x)) elementwise per channel, bf16 in/out (frequency model.py:14-16) */
 int combat_elu_affine(const void *x, int64_t rows, int32_t C, const float *scale, const float *shift, void *out,
                       void *stream);
+/* out = lrelu(x * scale[g][c] + shift[g][c], slope) as a bf16 tensor, g = row / group_rows (0: one
+ * group = BatchNorm; H*W: per image = InstanceNorm); scale/shift NULL: the activation alone.  The
+ * train-mode normalisation + activation (preact_resnet.py:33,36; networks/models.py:322-340) that the
+ * convolution prologues otherwise recompute per use: materialised once, the 3x3 forward and the
+ * weight-gradient passes then take both operands by LDS-DMA. */
+int combat_affine_act(const void *x, int64_t rows, int32_t C, const float *scale, const float *shift,
+                      int64_t group_rows, float slope, void *out, void *stream);
 /* DCT-II of the truncated 0..255 image (train_generator.py:245): x fp32 NCHW in [-1,1] ->
  * out bf16 NHWC c8 hi/lo of D*q*D^T, q = trunc((x+1)/2*255); D fp32 [hw][hw] */
 int combat_dct_u8(const float *x, const float *D, int32_t n, int32_t hw, void *out_c8, void *stream);

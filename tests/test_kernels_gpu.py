@@ -416,6 +416,49 @@ def test_wgrad3x3_halo_kernel(ops, n, hw, c, k, per_image):
     assert rel_l2(dw3, ref) < 2e-3
 
 
+@pytest.mark.parametrize("n,hw,c,k", [(4, 32, 64, 64), (3, 16, 128, 64), (5, 8, 64, 128), (6, 4, 128, 128), (9, 4, 64, 64),
+                                      (7, 2, 128, 64), (33, 2, 64, 64), (16, 16, 64, 64)])
+def test_wgrad3x3_dma_kernel(ops, n, hw, c, k):
+    """3x3/s1 weight gradient of an already-activated input (no prologue): both operands DMA'd into
+    LDS.  All tile geometries (16-, 8-, 4- and 2-pixel-wide patches, several images per patch, ragged N),
+    automatic and explicit pixel-range split; cross-checked against the generic kernel."""
+    x = torch.randn(n, c, hw, hw, generator=g(55))
+    w, pc = make_conv(ops, k, c, 3, 1, 1, 56)
+    dy = torch.randn(n, k, hw, hw, generator=g(57))
+    ref = torch.nn.grad.conv2d_weight(rb(x), (k, c, 3, 3), rb(dy), padding=1).permute(0, 2, 3, 1).reshape(k, 9, c)
+    xd, dyd = nhwc(x), nhwc(dy)
+    for split, ws in ((0, None), (3, None), (-1, None), (0, True), (5, True)):   # ws: slab stores + reduction launch
+        dw = torch.zeros(k, 9, c, device="cuda")
+        ops.conv_wgrad(xd, dyd, pc, dw, split=split, workspace=ws)
+        assert rel_l2(dw, ref) < 2e-3, (split, ws)
+
+
+@pytest.mark.parametrize("per_image,with_affine", [(False, True), (True, True), (False, False)])
+def test_affine_act_matches_the_conv_prologue(ops, per_image, with_affine):
+    """combat_affine_act materialises what a convolution prologue computes: a prologue-free convolution of
+    its output must equal the convolution with the prologue, bit for bit."""
+    from combat_amd._lib import lib
+    n, hw, c, k = 5, 8, 64, 64
+    x = torch.randn(n, c, hw, hw, generator=g(60))
+    shape = (n, c) if per_image else (c,)
+    sc, sh = torch.rand(shape, generator=g(61)) + 0.5, torch.randn(shape, generator=g(62)) * 0.3
+    aff = ops.Affine(dev(sc) if with_affine else None, dev(sh) if with_affine else None, c if per_image else 0, True, 0.2)
+    xd = nhwc(x)
+    act = torch.empty_like(xd)
+    ops.check(lib.combat_affine_act(xd.data_ptr(), n * hw * hw, c, aff.scale.data_ptr() if with_affine else None,
+                                    aff.shift.data_ptr() if with_affine else None, hw * hw if per_image else 0, 0.2,
+                                    act.data_ptr(), torch.cuda.current_stream().cuda_stream), "combat_affine_act")
+    w, pc = make_conv(ops, k, c, 3, 1, 1, 63)
+    y_pro = torch.empty(n, hw, hw, k, dtype=bf16, device="cuda")
+    y_act = torch.empty(n, hw, hw, k, dtype=bf16, device="cuda")
+    ops.conv_launch(ops.conv_args(xd, y_pro, pc, 0, pro=aff, tile=9))
+    ops.conv_launch(ops.conv_args(act, y_act, pc, 0, tile=9))
+    assert torch.equal(y_pro, y_act)
+    bsc = (sc[:, :, None, None] if per_image else sc[None, :, None, None]) if with_affine else 1.0
+    bsh = (sh[:, :, None, None] if per_image else sh[None, :, None, None]) if with_affine else 0.0
+    assert rel_l2(nchw(act), F.leaky_relu(rb(x) * bsc + bsh, 0.2)) < 4e-3
+
+
 def test_pack_weights_layouts(ops):
     k, c = 24, 16
     w = torch.randn(k, c, 3, 3, generator=g(50))
