@@ -23,7 +23,6 @@ struct HeadFwdArgs {
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled features [in]
-    __shared__ float red[256];
     __shared__ float lg[kMaxClasses];
     const int tid = threadIdx.x, img = blockIdx.x;
     const int ph = a.hw / 4, in = a.C * ph * ph;
@@ -40,21 +39,21 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
         if (a.pooled) a.pooled[(long)img * in + i] = s;
     }
     __syncthreads();
-    for (int j = 0; j < a.classes; ++j) {
-        float s = 0.f;
-        for (int i = tid; i < in; i += 256) s = fmaf(sm[i], a.W[(long)j * in + i], s);
-        red[tid] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) red[tid] += red[tid + o];
-            __syncthreads();
+    // one class per wave at a time: lane-strided dot product + in-wave butterfly (no workgroup barriers)
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int j = wv; j < a.classes; j += 4) {
+            float s = 0.f;
+            for (int i = lane; i < in; i += 64) s = fmaf(sm[i], a.W[(long)j * in + i], s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) {
+                lg[j] = s + a.b[j];
+                a.logits[(long)img * a.classes + j] = lg[j];
+            }
         }
-        if (tid == 0) {
-            lg[j] = red[0] + a.b[j];
-            a.logits[(long)img * a.classes + j] = lg[j];
-        }
-        __syncthreads();
     }
+    __syncthreads();
     if (tid == 0) {
         float mx = lg[0];
         int am = 0;
@@ -81,6 +80,7 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float *__restr
                                                             int n, int hw, int C, int classes,
                                                             const float *__restrict__ W, float *__restrict__ dlogits,
                                                             __bf16 *__restrict__ d_feat) {
+    extern __shared__ __attribute__((aligned(16))) float dsm[];  // gradient of the pooled features [in]
     __shared__ float dl[kMaxClasses];
     const int tid = threadIdx.x, img = blockIdx.x;
     if (tid == 0) {
@@ -99,7 +99,13 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float *__restr
     __syncthreads();
     if (!d_feat) return;
     const int ph = hw / 4, in = C * ph * ph;
-    // thread per (pixel, 8-channel chunk) of the feature map
+    // gradient of every pooled feature (coalesced reads of W along i), then broadcast over its 4x4 window
+    for (int i = tid; i < in; i += 256) {
+        float s = 0.f;
+        for (int j = 0; j < classes; ++j) s = fmaf(dl[j], W[(long)j * in + i], s);
+        dsm[i] = s * (1.f / 16.f);
+    }
+    __syncthreads();
     const int nch = C >> 3;
     for (int t = tid; t < hw * hw * nch; t += 256) {
         const int ch = (t % nch) * 8, px = t / nch;
@@ -107,31 +113,29 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float *__restr
         const int py = y >> 2, pxx = x >> 2;
         float o[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int i = ((ch + e) * ph + py) * ph + pxx;
-            float s = 0.f;
-            for (int j = 0; j < classes; ++j) s = fmaf(dl[j], W[(long)j * in + i], s);
-            o[e] = s * (1.f / 16.f);
-        }
+        for (int e = 0; e < 8; ++e) o[e] = dsm[((ch + e) * ph + py) * ph + pxx];
         *reinterpret_cast<uint4 *>(d_feat + (((long)img * hw + y) * hw + x) * C + ch) = pack8(o);
     }
 }
 
-// dW[j][i] = sum_s dlogits[s][j] * pooled[s][i];  db[j] = sum_s dlogits[s][j]
+// dW[j][i] += sum_s dlogits[s][j] * pooled[s][i];  db[j] += sum_s dlogits[s][j]   (blockIdx.z: sample range;
+// the gradient buffer is zeroed at the start of every backward pass)
 __global__ __launch_bounds__(256) void head_bwd_w_kernel(const float *__restrict__ dlogits,
                                                          const float *__restrict__ pooled, int n, int in, int classes,
                                                          float *__restrict__ dW, float *__restrict__ db) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int j = blockIdx.y;
+    const int per = (n + gridDim.z - 1) / gridDim.z;
+    const int s0 = blockIdx.z * per, s1 = s0 + per < n ? s0 + per : n;
     if (i < in) {
         float s = 0.f;
-        for (int smp = 0; smp < n; ++smp) s = fmaf(dlogits[(long)smp * classes + j], pooled[(long)smp * in + i], s);
-        dW[(long)j * in + i] = s;
+        for (int smp = s0; smp < s1; ++smp) s = fmaf(dlogits[(long)smp * classes + j], pooled[(long)smp * in + i], s);
+        atomicAdd(dW + (long)j * in + i, s);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
-        for (int smp = 0; smp < n; ++smp) s += dlogits[(long)smp * classes + j];
-        db[j] = s;
+        for (int smp = s0; smp < s1; ++smp) s += dlogits[(long)smp * classes + j];
+        atomicAdd(db + j, s);
     }
 }
 
@@ -168,12 +172,14 @@ extern "C" int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32
     if (classes <= 0 || classes > kMaxClasses) return COMBAT_EINVAL;
     if (dW && (!db || !pooled)) return COMBAT_EINVAL;
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(n), dim3(256), 0, st, logits, targets, loss_weight, n, hw, C, classes,
-                       W, dlogits, reinterpret_cast<__bf16 *>(d_feat));
+    const int in_ = C * (hw / 4) * (hw / 4);
+    if (in_ * 4 > 60 * 1024) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(n), dim3(256), in_ * 4, st, logits, targets, loss_weight, n, hw, C,
+                       classes, W, dlogits, reinterpret_cast<__bf16 *>(d_feat));
     CB_LAUNCH_CHECK();
     if (dW) {
         const int in = C * (hw / 4) * (hw / 4);
-        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((in + 255) / 256, classes), dim3(256), 0, st, dlogits, pooled, n, in,
+        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((in + 255) / 256, classes, 8), dim3(256), 0, st, dlogits, pooled, n, in,
                            classes, dW, db);
         CB_LAUNCH_CHECK();
     }

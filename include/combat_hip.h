@@ -292,7 +292,8 @@ int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const float *param
  * correct2 += #argmax==targets2 (both optional; classes <= 16).
  * Backward: dlogits fp32 [n][classes] = loss_weight/n * (softmax - onehot);
  * d_feat bf16 [n][hw][hw][C] = dlogits W / 16 (may be NULL); and (if dW != NULL)
- * dW fp32 [classes][in] = dlogits^T pooled, db fp32 [classes] (both overwritten).
+ * dW fp32 [classes][in] += dlogits^T pooled, db fp32 [classes] += column sums (accumulated with fp32
+ * atomics over sample ranges, like the convolution weight gradients: zero them first).
  * ------------------------------------------------------------------------------------------ */
 int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t C, const float *W, const float *b,
                     int32_t classes, const int64_t *targets, float loss_weight, float *pooled, float *logits,

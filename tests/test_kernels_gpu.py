@@ -691,7 +691,7 @@ def test_head_forward_backward(ops, hw, classes):
     assert int(correct) == int((lg.argmax(1) == t).sum())
     dl = torch.empty(n, classes, device="cuda")
     dfeat = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
-    dw, db = torch.empty_like(dev(w)), torch.empty(classes, device="cuda")
+    dw, db = torch.zeros_like(dev(w)), torch.zeros(classes, device="cuda")   # accumulated into
     ops.head_bwd(pooled, n, hw, c, dev(w), logits, dev(t), 0.8, dl, dfeat, dw, db)
     assert rel_l2(nchw(dfeat), fr.grad) < 4e-3
     assert rel_l2(dw, wr.grad) < 1e-5 and rel_l2(db, br.grad) < 1e-5
