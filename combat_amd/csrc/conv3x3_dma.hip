@@ -332,7 +332,8 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     // ---- epilogue: accumulators -> this wave's fp32 LDS image (the operand images are dead once every
     // wave has passed the barrier) -> row-major items
     block_barrier();
-    float *ep = reinterpret_cast<float *>(smem) + wid * (32 * T::EPS);
+    constexpr int EPW = 32 * T::EPS > 64 * 20 ? 32 * T::EPS : 64 * 20;   // floats per wave: tile image / statistics scratch
+    float *ep = reinterpret_cast<float *>(smem) + wid * EPW;
 #pragma unroll
     for (int i = 0; i < T::FN; ++i)
 #pragma unroll
@@ -504,7 +505,7 @@ template <int BN, int TW, int HB>
 int launch_hb(const DmaParams &p, hipStream_t st) {
     using G = DGeo<TW>;
     constexpr int stage = HB * G::HBYTES + 3 * BN * 128;
-    constexpr int ep = 128 * (BN + 4) * 4;
+    constexpr int ep = 4 * 4 * (32 * (BN + 4) > 64 * 20 ? 32 * (BN + 4) : 64 * 20);
     constexpr int smem = stage > ep ? stage : ep;
     auto kern = conv3x3_dma_kernel<BN, TW, HB>;
     static bool attr_set = false;
@@ -525,7 +526,12 @@ int launch(const combat_conv_args *a, hipStream_t st) {
     return p.nchunks == 1 ? launch_hb<BN, TW, 1>(p, st) : launch_hb<BN, TW, 2>(p, st);
 }
 
-int tile_bn(int tile) { return tile == COMBAT_TILE_D128x64 ? 64 : 0; }
+int tile_bn(int tile) { return tile == COMBAT_TILE_D128x64 ? 64 : (tile == COMBAT_TILE_D128x32 ? 32 : 0); }
+
+int tiles_m_of(const combat_conv_args *a) {
+    const int tw = geo_tw(a), th = tw == 4 ? 4 : 8, ti = 128 / (tw * th);
+    return (a->W / tw) * (a->H / th) * ((a->N + ti - 1) / ti);
+}
 
 }  // namespace
 
@@ -537,16 +543,17 @@ int conv3x3d_pick(const combat_conv_args *a) {
         const int bn = tile_bn(a->tile);
         return bn && applicable(a, bn) ? a->tile : 0;
     }
-    return applicable(a, 64) ? COMBAT_TILE_D128x64 : 0;
+    if (!applicable(a, 64)) return applicable(a, 32) ? COMBAT_TILE_D128x32 : 0;
+    // skinny layers: 32-channel tiles double the workgroup count when 64-channel tiles cannot fill the chip
+    return tiles_m_of(a) * (a->K / 64) < 192 ? COMBAT_TILE_D128x32 : COMBAT_TILE_D128x64;
 }
 
 int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {
     const int bn = tile_bn(tile);
     if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
     const int tw = geo_tw(a);
-    const int th = tw == 4 ? 4 : 8, ti = 128 / (tw * th);
-    const int tiles_m = (a->W / tw) * (a->H / th) * ((a->N + ti - 1) / ti);
-    *rows = tiles_m * 4;   // one row per wave = 32 pixels
+    const int th = tw == 4 ? 4 : 8;
+    *rows = tiles_m_of(a) * 4;   // one row per wave = 32 pixels
     *rows_per_image = ((tw * th) % 32 == 0) ? (a->H * a->W) / 32 : 0;
     return COMBAT_OK;
 }
@@ -555,7 +562,12 @@ int conv3x3d_launch(const combat_conv_args *a, int tile, hipStream_t st) {
     const int bn = tile_bn(tile);
     if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
     const int tw = geo_tw(a);
-    if (tw == 16) return launch<64, 16>(a, st);
-    if (tw == 8) return launch<64, 8>(a, st);
-    return launch<64, 4>(a, st);
+    if (bn == 64) {
+        if (tw == 16) return launch<64, 16>(a, st);
+        if (tw == 8) return launch<64, 8>(a, st);
+        return launch<64, 4>(a, st);
+    }
+    if (tw == 16) return launch<32, 16>(a, st);
+    if (tw == 8) return launch<32, 8>(a, st);
+    return launch<32, 4>(a, st);
 }

@@ -331,7 +331,8 @@ extern "C" int combat_conv_stats_granule(int tile) {
         case COMBAT_TILE_128x16:
         case COMBAT_TILE_H128x128:
         case COMBAT_TILE_H128x64:
-        case COMBAT_TILE_D128x64: return 32;
+        case COMBAT_TILE_D128x64:
+        case COMBAT_TILE_D128x32: return 32;
         case COMBAT_TILE_64x64:
         case COMBAT_TILE_64x128:
         case COMBAT_TILE_H64x64: return 16;

@@ -117,6 +117,7 @@ typedef struct combat_conv_args {
  * and no tanh: both operands go global -> LDS by DMA (buffer_load ... lds), 128 pixels x 64
  * channels per workgroup (conv3x3_dma.hip) */
 #define COMBAT_TILE_D128x64 10
+#define COMBAT_TILE_D128x32 11   /* skinny layers: twice the workgroups */
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);
 /* tile the launcher would pick for these args (a->tile honoured) and its stats granule */
