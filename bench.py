@@ -86,6 +86,25 @@ def conv_flops(a):
     return 2.0 * pix * pc.K * pc.c_real * pc.taps
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
+    per the gfx950 correction + WRITE_SIZE, separate --pmc runs; profiles/r01_f_pmc_hbm_traffic.csv):
+    PMC counters cannot be collected from inside this process.  None if the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.csv")
+    try:
+        tot = cnt = 0.0
+        for line in open(path):
+            if line.startswith("#") or line.startswith("kernel,"):
+                continue
+            f = line.rstrip("\n").rsplit(",", 6)
+            if kernel_prefix in f[0]:
+                tot += float(f[1]) * float(f[6]) * 1024.0
+                cnt += float(f[1])
+        return round(tot / cnt) if cnt else None
+    except OSError:
+        return None
+
+
 def roofline_from(prof):
     from combat_amd._lib import lib
     import ctypes
@@ -100,7 +119,9 @@ def roofline_from(prof):
     achieved = fl / sec / 1e12
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+        "traffic": pmc_traffic(TILE_NAMES.get(tile, str(tile)).split(">")[0] + ","),
+        "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r01_f_pmc_hbm_traffic.csv)",
         "kernel": TILE_NAMES.get(tile, str(tile)), "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
         "gflop_per_launch": round(fl / cnt / 1e9, 3),
         "all_conv_tiles": {TILE_NAMES.get(t, str(t)): {"launches": c, "avg_us": round(s / c * 1e6, 2),
