@@ -34,7 +34,7 @@ PEAK_BF16_TFLOPS = 2500.0
 TILE_NAMES = {1: "conv_gemm_kernel<128,128>", 2: "conv_gemm_kernel<128,64>", 3: "conv_gemm_kernel<64,64>",
               4: "conv_gemm_kernel<128,16>", 5: "conv_gemm_kernel<64,128>",
               6: "conv3x3_halo1_kernel<256,64>", 7: "conv3x3_halo1_kernel<128,128>", 8: "conv3x3_halo1_kernel<128,64>",
-              9: "conv3x3_halo_kernel<64,64>", 10: "conv3x3_dma_kernel<64>", 11: "conv3x3_dma_kernel<32>"}
+              9: "conv3x3_halo_kernel<64,64>", 10: "conv3x3_dma_kernel<64>", 11: "conv3x3_dma_kernel<32>", 12: "conv_gather_dma_kernel<64>", 13: "conv_gather_dma_kernel<32>", 14: "conv3x3_dma_kernel<64,256px>"}
 
 
 def log(msg):

@@ -600,7 +600,7 @@ bool applicable(const combat_conv_args *a) {
 // tile id (COMBAT_TILE_H*) the halo kernel would use for these args, or 0 if it does not apply
 int conv3x3_pick(const combat_conv_args *a) {
     if (const int d = conv3x3d_pick(a)) return d;
-    if (a->tile >= COMBAT_TILE_D128x64) return 0;
+    if (a->tile >= COMBAT_TILE_D128x64) return 0;   // (the gather tiles 12/13 are not 3x3 tiles: the caller tries them next)
     if (!applicable(a)) return 0;
     if (a->tile) {
         for (const Cand &c : kCands)

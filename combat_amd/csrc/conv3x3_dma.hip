@@ -20,7 +20,7 @@
 // The fused epilogue (bias, residuals, activation mask, normalisation statistics: the same semantics
 // as conv_common.hpp's) is wave-private: each wave transposes its 32 pixels x BN channels through LDS
 // and its operand fetches are issued four steps before the main loop ends.
-#include "conv_common.hpp"
+#include "conv_dma_epilogue.hpp"
 
 #ifdef COMBAT_STAMPS   // in-kernel phase stamps of profiling builds: the buffer pointer travels as a kernel argument
 static unsigned long long *g_stamps_dma_host = nullptr;
@@ -38,7 +38,7 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-constexpr unsigned kOob = 0x40000000u;  // buffer offset beyond every tensor on this path: reads as zeros
+constexpr unsigned kOob = kDmaOob;
 
 struct DmaParams {
     combat_conv_args a;
@@ -48,22 +48,23 @@ struct DmaParams {
     unsigned long long *stamps;   // profiling builds only
 };
 
-// geometry class of a 128-pixel tile, keyed by the tile width
-template <int TW>
+// geometry class of a tile of 32 * NW pixels (NW waves of 32 pixels), keyed by the tile width
+template <int TW, int NW>
 struct DGeo {
-    static constexpr int TH = TW == 4 ? 4 : 8;
-    static constexpr int TI = 128 / (TW * TH);
+    static constexpr int BM = 32 * NW;
+    static constexpr int TH = TW == 16 ? BM / 16 : (TW == 8 ? 8 : 4);
+    static constexpr int TI = BM / (TW * TH);
     static constexpr int HH = TH + 2;
     // halo row pitch in pixels.  The slot rotation is keyed on the halo COLUMN (hx & 6), so a tap's row
     // offset (a multiple of the pitch) never changes it; the 16 pixels of a fragment lie in one halo
     // row (TW 16) or in rows whose equal columns fall into the same rotation class (TW 8), which keeps
     // ds_read_b128 conflict-free for any pitch.  TW 4 keeps the power-of-two pitch.
     static constexpr int HWP = TW == 4 ? 8 : TW + 2;
-    static constexpr int HROWS = TI * HH * HWP;     // LDS rows (pixels) of one halo image
-    static constexpr int HPW = (HROWS + 31) / 32;   // 1-KiB DMA pieces (8 rows) per wave
-    static constexpr int HBYTES = HPW * 4 * 1024;   // every wave issues the same number of pieces
+    static constexpr int HROWS = TI * HH * HWP;                  // LDS rows (pixels) of one halo image
+    static constexpr int HPW = (HROWS + 8 * NW - 1) / (8 * NW);  // 1-KiB DMA pieces (8 rows) per wave
+    static constexpr int HBYTES = HPW * NW * 1024;               // every wave issues the same number of pieces
     static constexpr int TW_SHIFT = TW == 16 ? 4 : (TW == 8 ? 3 : 2);
-    static constexpr int TH_SHIFT = TH == 8 ? 3 : 2;
+    static constexpr int TH_SHIFT = TH == 16 ? 4 : (TH == 8 ? 3 : 2);
 };
 
 template <int VM>
@@ -79,12 +80,12 @@ __device__ __forceinline__ void block_barrier() {
 
 // HB = halo images in LDS: 1 for single-chunk layers (C = 64), 2 otherwise (the next chunk's patch is
 // DMA'd while the current one is consumed)
-template <int BN, int TW, int HB>
+// NW = waves per workgroup (4: 128-pixel tiles; 8: 256-pixel tiles, which halve the weight DMA per MFMA)
+template <int BN, int TW, int HB, int NW>
 __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
-    constexpr int BM = 128;
-    using T = TileCfg<BM, BN, 4>;   // four waves along the pixels: a wave owns 32 pixels x all BN channels
-    using G = DGeo<TW>;
-    constexpr int WPW = BN / 32;            // weight DMA pieces per wave and step
+    using T = TileCfg<128, BN, 4>;  // shape of ONE wave's share: 32 pixels x all BN channels (whatever NW is)
+    using G = DGeo<TW, NW>;
+    constexpr int WPW = BN / (8 * NW);      // weight DMA pieces per wave and step
     constexpr int WBYTES = BN * 128;        // one ring slot
     constexpr int HBYTES = G::HBYTES;
     constexpr int HPW = G::HPW;
@@ -115,7 +116,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     unsigned hvoff[HPW];
 #pragma unroll
     for (int j = 0; j < HPW; ++j) {
-        const int row = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
+        const int row = (wid + NW * j) * 8 + (lane >> 3), slot = lane & 7;
         const int hx = row % G::HWP, t = row / G::HWP;
         const int hy = t % G::HH, ti = t / G::HH;
         const int chunk = (slot - (hx & 6)) & 7;
@@ -126,14 +127,14 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     unsigned wvoff[WPW];
 #pragma unroll
     for (int j = 0; j < WPW; ++j) {
-        const int n = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
+        const int n = (wid + NW * j) * 8 + (lane >> 3), slot = lane & 7;
         const int chunk = (slot - (n & 6)) & 7;
         wvoff[j] = (unsigned)(((n0 + n) * a.kpad + chunk * 8) * 2);
     }
     auto issue_h = [&](int cc, int hbuf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < HPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(halo + hbuf * HBYTES + (wid + 4 * j) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(halo + hbuf * HBYTES + (wid + NW * j) * 1024), 16,
                                                      hvoff[j], cc * 128, 0, 0);
     };
     // weights of loop position t of chunk cc (dgrad walks the filter taps mirrored: tap 8 - t)
@@ -142,7 +143,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         const int soff = (tap * C + cc * 64) * 2;
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(wring + slot * WBYTES + (wid + 4 * j) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(wring + slot * WBYTES + (wid + NW * j) * 1024), 16,
                                                      wvoff[j], soff, 0, 0);
     };
 
@@ -202,52 +203,18 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     // an out-of-range offset / empty resource: loads give zeros, stores are dropped); they are issued
     // in the middle of the main loop's last chunk, so that their latency is covered by the remaining
     // MFMA steps -- the counted waits of those steps include them.
-    const int fr = lane & 15, fq = lane >> 4;
-    const int K = a.K;
-    const unsigned dst_bytes = (unsigned)(a.N * p.PQ) * (unsigned)K * 2u;
-    const __amdgpu_buffer_rsrc_t r_pre = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_pre), 0, a.add_pre ? dst_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.mask_x), 0, a.mask_x ? dst_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_post = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_post), 0, a.add_post ? dst_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst ? dst_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc(a.act_dst, 0, a.act_dst ? dst_bytes : 0u, 0x00020000);
-    constexpr int NC = T::NC;                // 16-byte chunks per dst row of the tile
-    constexpr int EQ = 32 * NC / 64;         // (row, chunk) items per lane
-    const int ec = lane % NC;                // this lane's chunk: channels n0 + 8 ec .. + 7
-    unsigned evoff[EQ];
-    bool ragged = false;                     // does this wave touch rows beyond the last image?
-#pragma unroll
-    for (int q = 0; q < EQ; ++q) {
-        const int row = wid * 32 + (q * 64 + lane) / NC;
+    // ---- fused epilogue (conv_dma_epilogue.hpp): operand fetches are issued PF_T taps before the loop ends
+    using EC = EpiCfg<T>;
+    constexpr int NPF = EC::NPF;
+    const unsigned dst_bytes = (unsigned)(a.N * p.PQ) * (unsigned)a.K * 2u;
+    EpiRegs<T> epi;
+    epi_init<T>(epi, lane, wid, n0, [&](int row) -> long {
         const int tx = row & (TW - 1), ty = (row >> G::TW_SHIFT) & (G::TH - 1);
         const int img = img0 + (row >> (G::TW_SHIFT + G::TH_SHIFT));
-        evoff[q] = img < a.N ? (unsigned)((((img * H + oy0 + ty) * W + ox0 + tx) * K + n0 + ec * 8) * 2) : kOob;
-    }
-    if (G::TI > 1) ragged = img0 + G::TI > a.N;
-    // per-channel tables of this lane's 8 channels (empty resource = absent table = zeros)
-    const unsigned tab_bytes = (unsigned)K * 4u;
-    const bool kind2 = a.stats_kind == 2;
-    // one (scale, shift) table pair travels with the operand prefetch: the mask tables (input-gradient
-    // passes) or the activation-output tables (forward passes) -- a launch never has both (applicable())
-    const float *tab_sc = a.mask_x ? a.mask_scale : a.act_scale, *tab_sh = a.mask_x ? a.mask_shift : a.act_shift;
-    const __amdgpu_buffer_rsrc_t r_msc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab_sc), 0, tab_sc ? tab_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_msh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab_sh), 0, tab_sh ? tab_bytes : 0u, 0x00020000);
-    constexpr int NPF = 3 * EQ + 4;   // operand + mask-table fetches in flight
-    u32x4_t e_pre[EQ], e_x[EQ], e_post[EQ];
-    f32x4_t t_msc[2], t_msh[2];
-    auto epilogue_fetch = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int q = 0; q < EQ; ++q) {
-            e_pre[q] = __builtin_amdgcn_raw_buffer_load_b128(r_pre, evoff[q], 0, 0);
-            e_x[q] = __builtin_amdgcn_raw_buffer_load_b128(r_x, evoff[q], 0, 0);
-            e_post[q] = __builtin_amdgcn_raw_buffer_load_b128(r_post, evoff[q], 0, 0);
-        }
-        const int tb = (n0 + ec * 8) * 4;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            t_msc[h] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_msc, tb + 16 * h, 0, 0));
-            t_msh[h] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_msh, tb + 16 * h, 0, 0));
-        }
-    };
+        return img < a.N ? (long)((img * H + oy0 + ty) * W + ox0 + tx) * a.K : -1;
+    });
+    const bool ragged = G::TI > 1 && img0 + G::TI > a.N;
+    auto epilogue_fetch = [&]() __attribute__((always_inline)) { epi_fetch<T>(epi, a, dst_bytes, lane, n0); };
 
     // ---- main loop, software pipelined.  Loop position t of a chunk = filter tap; its weights live in
     // ring slot t % 3 and are DMA'd three positions ahead.  A position is two k-steps; its fragments
@@ -332,133 +299,14 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     // ---- epilogue: accumulators -> this wave's fp32 LDS image (the operand images are dead once every
     // wave has passed the barrier) -> row-major items
     block_barrier();
-    constexpr int EPW = 32 * T::EPS > 64 * 20 ? 32 * T::EPS : 64 * 20;   // floats per wave: tile image / statistics scratch
-    float *ep = reinterpret_cast<float *>(smem) + wid * EPW;
-#pragma unroll
-    for (int i = 0; i < T::FN; ++i)
-#pragma unroll
-        for (int j = 0; j < T::FM; ++j)
-            *reinterpret_cast<f32x4_t *>(ep + (j * 16 + fr) * T::EPS + i * 16 + fq * 4) = acc[i][j];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS accesses execute in order
-    DSTAMP(5);
-
-    const bool has_mask = a.mask_x != nullptr, has_scale = a.mask_scale != nullptr, has_act = a.act_dst != nullptr;
-    const bool mul_scale = a.mask_mul_scale != 0;
-    const bool plain_test = !has_scale || a.mask_activated;   // kept-test on mask_x itself
-    const int n = n0 + ec * 8;
-    float bias8[8], msc[8], msh[8], hrs[8], hmn[8], tsc[8], tsh[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bias8[e] = hrs[e] = hmn[e] = 0.f;
-        tsc[e] = t_msc[e >> 2][e & 3];   // mask tables or activation-output tables
-        tsh[e] = t_msh[e >> 2][e & 3];
-        msc[e] = plain_test ? 1.f : tsc[e];
-        msh[e] = plain_test ? 0.f : tsh[e];
-    }
-    if (a.bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
-    if (kind2) {
-        load8f(a.xh_rstd + n, hrs);
-        load8f(a.xh_mean + n, hmn);
-    }
-    float mfac[8];   // factor of a kept element: the scale (BatchNorm backward) or 1
-#pragma unroll
-    for (int e = 0; e < 8; ++e) mfac[e] = mul_scale ? tsc[e] : 1.f;
-    float s1[8], s2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    u32x4_t packed[EQ], packed_act[EQ];
-#pragma unroll
-    for (int q = 0; q < EQ; ++q) {
-        const int r = (q * 64 + lane) / NC;
-        float v[8], t[8], xm[8];
-        load8f(ep + r * T::EPS + ec * 8, v);
-        unpack8v(e_pre[q], t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias8[e] + t[e];
-        if (has_mask) {
-            unpack8v(e_x[q], xm);
-#pragma unroll
-            for (int e = 0; e < 8; ++e)   // msc = 1, msh = 0 without a table
-                v[e] *= fmaf(xm[e], msc[e], msh[e]) > 0.f ? mfac[e] : mfac[e] * a.mask_slope;
-        }
-        unpack8v(e_post[q], t);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += t[e];
-        packed[q] = pack8v(v);
-        if (has_act) {   // the next layer's (eval BatchNorm + ReLU) prologue, applied to the stored value
-            float y[8];
-            unpack8v(packed[q], y);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float qa = fmaf(y[e], tsc[e], tsh[e]);
-                y[e] = qa > 0.f ? qa : qa * a.act_slope;
-            }
-            packed_act[q] = pack8v(y);
-        }
-        if (a.stats_kind) {
-            float vr[8];
-            unpack8v(packed[q], vr);
-            if (ragged && evoff[q] == kOob) {   // rows beyond the last image count as zeros
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vr[e] = 0.f;
-            }
-            if (kind2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1[e] += vr[e];
-                    s2[e] = fmaf(vr[e], (xm[e] - hmn[e]) * hrs[e], s2[e]);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1[e] += vr[e];
-                    s2[e] = fmaf(vr[e], vr[e], s2[e]);
-                }
-            }
-        }
-    }
-    DSTAMP(6);
-#pragma unroll
-    for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed[q], r_dst, evoff[q], 0, 0);
-    if (has_act) {
-#pragma unroll
-        for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed_act[q], r_act, evoff[q], 0, 0);
-    }
-    DSTAMP(7);
-    if (a.stats_kind) {
-        // one statistics row per wave (32 pixels).  Lanes with equal chunk differ by multiples of NC:
-        // one pass through the wave's LDS image ([lane][16] partial sums; lane -> (chunk, value pair))
-        // instead of log2(64 / NC) dependent cross-lane shuffles of 16 values each.
-        float *sp = ep + lane * 20;   // 16 values + pad: 80-byte pitch keeps the 16-byte stores conflict-free
-        *reinterpret_cast<f32x4_t *>(sp) = f32x4_t{s1[0], s1[1], s1[2], s1[3]};
-        *reinterpret_cast<f32x4_t *>(sp + 4) = f32x4_t{s1[4], s1[5], s1[6], s1[7]};
-        *reinterpret_cast<f32x4_t *>(sp + 8) = f32x4_t{s2[0], s2[1], s2[2], s2[3]};
-        *reinterpret_cast<f32x4_t *>(sp + 12) = f32x4_t{s2[4], s2[5], s2[6], s2[7]};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // NC chunks x 16 values = NC * 16 sums; lane handles chunk (lane % NC), values vg .. vg + VPL - 1
-        constexpr int VPL = NC * 16 / 64;            // values per lane (2 or 4)
-        const int vg = (lane / NC) * VPL;
-        float tot[VPL];
-#pragma unroll
-        for (int u = 0; u < VPL; ++u) tot[u] = 0.f;
-#pragma unroll
-        for (int src = 0; src < 64 / NC; ++src) {
-            const float *rp = ep + (src * NC + ec) * 20 + vg;
-#pragma unroll
-            for (int u = 0; u < VPL; ++u) tot[u] += rp[u];
-        }
-        // value index v: 0..7 -> sum, 8..15 -> second moment, of channel n + (v & 7)
-        float *orow = a.stats + ((size_t)(tile_m * 4 + wid) * 2 + (vg >> 3)) * K + n + (vg & 7);
-#pragma unroll
-        for (int u = 0; u < VPL; ++u) orow[u] = tot[u];
-    }
+    epi_finish<T>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged);
     DSTAMP(4);
 }
 
 // (the body is a device function: the host pass cannot see the buffer-resource type it uses)
-template <int BN, int TW, int HB>
-__global__ __launch_bounds__(256, HB == 1 ? 3 : 2) void conv3x3_dma_kernel(const DmaParams p) {
-    conv3x3_dma_body<BN, TW, HB>(p);
+template <int BN, int TW, int HB, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HB == 1 ? 3 : 2)) void conv3x3_dma_kernel(const DmaParams p) {
+    conv3x3_dma_body<BN, TW, HB, NW>(p);
 }
 
 int geo_tw(const combat_conv_args *a) {
@@ -482,9 +330,9 @@ bool applicable(const combat_conv_args *a, int BN) {
     return geo_tw(a) != 0;
 }
 
-template <int TW>
+template <int TW, int NW>
 void fill(const combat_conv_args *a, int BN, DmaParams &p) {
-    using G = DGeo<TW>;
+    using G = DGeo<TW, NW>;
     p.a = *a;
     p.tiles_x = a->W / TW;
     p.tiles_y = a->H / G::TH;
@@ -501,35 +349,46 @@ void fill(const combat_conv_args *a, int BN, DmaParams &p) {
 #endif
 }
 
-template <int BN, int TW, int HB>
+template <int BN, int TW, int HB, int NW>
 int launch_hb(const DmaParams &p, hipStream_t st) {
-    using G = DGeo<TW>;
+    using G = DGeo<TW, NW>;
     constexpr int stage = HB * G::HBYTES + 3 * BN * 128;
-    constexpr int ep = 4 * 4 * (32 * (BN + 4) > 64 * 20 ? 32 * (BN + 4) : 64 * 20);
+    constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES / 4 * NW;
     constexpr int smem = stage > ep ? stage : ep;
-    auto kern = conv3x3_dma_kernel<BN, TW, HB>;
+    auto kern = conv3x3_dma_kernel<BN, TW, HB, NW>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return COMBAT_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * NW), smem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
 
-template <int BN, int TW>
+template <int BN, int TW, int NW>
 int launch(const combat_conv_args *a, hipStream_t st) {
     DmaParams p;
-    fill<TW>(a, BN, p);
-    return p.nchunks == 1 ? launch_hb<BN, TW, 1>(p, st) : launch_hb<BN, TW, 2>(p, st);
+    fill<TW, NW>(a, BN, p);
+    return p.nchunks == 1 ? launch_hb<BN, TW, 1, NW>(p, st) : launch_hb<BN, TW, 2, NW>(p, st);
 }
 
-int tile_bn(int tile) { return tile == COMBAT_TILE_D128x64 ? 64 : (tile == COMBAT_TILE_D128x32 ? 32 : 0); }
+int tile_bn(int tile) {
+    return tile == COMBAT_TILE_D128x64 || tile == COMBAT_TILE_D256x64 ? 64 : (tile == COMBAT_TILE_D128x32 ? 32 : 0);
+}
+int tile_bm(int tile) { return tile == COMBAT_TILE_D256x64 ? 256 : 128; }
 
-int tiles_m_of(const combat_conv_args *a) {
-    const int tw = geo_tw(a), th = tw == 4 ? 4 : 8, ti = 128 / (tw * th);
+// tile height for a tile of bm pixels (0: the geometry does not exist)
+int geo_th(const combat_conv_args *a, int bm) {
+    const int tw = geo_tw(a);
+    if (!tw || (tw == 4 && bm == 256)) return 0;   // 16 images of 4x4 per tile: two halo images would not fit LDS
+    const int th = tw == 16 ? bm / 16 : (tw == 8 ? 8 : 4);
+    return a->H % th == 0 ? th : 0;
+}
+
+int tiles_m_of(const combat_conv_args *a, int bm = 128) {
+    const int tw = geo_tw(a), th = geo_th(a, bm), ti = bm / (tw * th);
     return (a->W / tw) * (a->H / th) * ((a->N + ti - 1) / ti);
 }
 
@@ -541,19 +400,22 @@ int tiles_m_of(const combat_conv_args *a) {
 int conv3x3d_pick(const combat_conv_args *a) {
     if (a->tile) {
         const int bn = tile_bn(a->tile);
-        return bn && applicable(a, bn) ? a->tile : 0;
+        return bn && applicable(a, bn) && geo_th(a, tile_bm(a->tile)) ? a->tile : 0;
     }
     if (!applicable(a, 64)) return applicable(a, 32) ? COMBAT_TILE_D128x32 : 0;
-    // skinny layers: 32-channel tiles double the workgroup count when 64-channel tiles cannot fill the chip
+    // skinny layers: 32-channel tiles double the workgroup count when 64-channel tiles cannot fill the
+    // chip.  (256-pixel tiles -- eight waves, half the weight DMA per MFMA -- exist for explicit requests
+    // only: measured 0-15 % slower than three co-resident 128-pixel workgroups on every layer shape.)
     return tiles_m_of(a) * (a->K / 64) < 192 ? COMBAT_TILE_D128x32 : COMBAT_TILE_D128x64;
 }
 
 int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {
     const int bn = tile_bn(tile);
     if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
-    const int tw = geo_tw(a);
-    const int th = tw == 4 ? 4 : 8;
-    *rows = tiles_m_of(a) * 4;   // one row per wave = 32 pixels
+    const int tw = geo_tw(a), bm = tile_bm(tile);
+    const int th = geo_th(a, bm);
+    if (!th) return COMBAT_EINVAL;
+    *rows = tiles_m_of(a, bm) * (bm / 32);   // one row per wave = 32 pixels
     *rows_per_image = ((tw * th) % 32 == 0) ? (a->H * a->W) / 32 : 0;
     return COMBAT_OK;
 }
@@ -562,12 +424,17 @@ int conv3x3d_launch(const combat_conv_args *a, int tile, hipStream_t st) {
     const int bn = tile_bn(tile);
     if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
     const int tw = geo_tw(a);
-    if (bn == 64) {
-        if (tw == 16) return launch<64, 16>(a, st);
-        if (tw == 8) return launch<64, 8>(a, st);
-        return launch<64, 4>(a, st);
+    if (!geo_th(a, tile_bm(tile))) return COMBAT_EINVAL;
+    if (tile == COMBAT_TILE_D256x64) {
+        if (tw == 16) return launch<64, 16, 8>(a, st);
+        return launch<64, 8, 8>(a, st);
     }
-    if (tw == 16) return launch<32, 16>(a, st);
-    if (tw == 8) return launch<32, 8>(a, st);
-    return launch<32, 4>(a, st);
+    if (bn == 64) {
+        if (tw == 16) return launch<64, 16, 4>(a, st);
+        if (tw == 8) return launch<64, 8, 4>(a, st);
+        return launch<64, 4, 4>(a, st);
+    }
+    if (tw == 16) return launch<32, 16, 4>(a, st);
+    if (tw == 8) return launch<32, 8, 4>(a, st);
+    return launch<32, 4, 4>(a, st);
 }

@@ -1,0 +1,201 @@
+// Fused epilogue of the DMA-staged convolution kernels (conv3x3_dma.hip, conv_gather_dma.hip): device
+// code only (it uses the buffer-resource type, which the host pass does not know; include it from
+// device function templates).
+//
+// A wave owns 32 pixels x BN channels (TileCfg<128, BN, 4>).  It transposes its accumulators through a
+// private LDS image (no workgroup barrier) so that every global access is 16 bytes of 8 consecutive
+// channels and NC lanes cover one pixel's contiguous bytes.  Residual / mask operands and the
+// (scale, shift) table pair come through buffer loads (rows outside the tensor and absent tensors use
+// an out-of-range offset / an empty resource: loads give zeros, stores are dropped), issued by
+// epi_fetch() some steps before the main loop ends so that their latency is covered by the remaining
+// MFMA steps; the fixed instruction count (EpiCfg::NPF) lets the main loop's counted vmcnt waits
+// include them.  Semantics = conv_common.hpp's conv_epilogue (bias, add_pre, mask, add_post,
+// statistics) plus the activated second output.
+#pragma once
+#include "conv_common.hpp"
+
+constexpr unsigned kDmaOob = 0x40000000u;  // buffer offset beyond every tensor on this path: reads as zeros
+
+template <typename T>
+struct EpiCfg {
+    static constexpr int NC = T::NC;              // 16-byte chunks per dst row of the tile
+    static constexpr int EQ = 32 * NC / 64;       // (row, chunk) items per lane
+    static constexpr int NPF = 3 * EQ + 4;        // operand + table fetches of epi_fetch()
+    static constexpr int EPW = 32 * T::EPS > 64 * 20 ? 32 * T::EPS : 64 * 20;   // floats per wave: tile image / statistics scratch
+    static constexpr int LDS_BYTES = 4 * 4 * EPW;
+};
+
+template <typename T>
+struct EpiRegs {   // plain data only
+    unsigned evoff[EpiCfg<T>::EQ];                // byte offset of this lane's items in the dst-shaped tensors (or kDmaOob)
+    u32x4_t e_pre[EpiCfg<T>::EQ], e_x[EpiCfg<T>::EQ], e_post[EpiCfg<T>::EQ];
+    f32x4_t t_sc[2], t_sh[2];                     // mask tables (input-gradient passes) or activation-output tables (forward)
+};
+
+// evoff[q] = row_off(tile row) * 2 + channel bytes; row_off(row) = element index of the row's dst pixel * K, or -1
+template <typename T, typename RowOff>
+__device__ __forceinline__ void epi_init(EpiRegs<T> &r, int lane, int wid, int n0, RowOff row_off) {
+    constexpr int NC = EpiCfg<T>::NC;
+    const int ec = lane % NC;
+#pragma unroll
+    for (int q = 0; q < EpiCfg<T>::EQ; ++q) {
+        const long e = row_off(wid * 32 + (q * 64 + lane) / NC);
+        r.evoff[q] = e >= 0 ? (unsigned)((e + n0 + ec * 8) * 2) : kDmaOob;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_fetch(EpiRegs<T> &r, const combat_conv_args &a, unsigned dst_bytes, int lane, int n0) {
+    const unsigned tab_bytes = (unsigned)a.K * 4u;
+    const __amdgpu_buffer_rsrc_t r_pre = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_pre), 0, a.add_pre ? dst_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.mask_x), 0, a.mask_x ? dst_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_post = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_post), 0, a.add_post ? dst_bytes : 0u, 0x00020000);
+    // one (scale, shift) table pair travels with the operand prefetch: the mask tables or the
+    // activation-output tables -- a launch never has both (the kernels' applicable())
+    const float *tab_sc = a.mask_x ? a.mask_scale : a.act_scale, *tab_sh = a.mask_x ? a.mask_shift : a.act_shift;
+    const __amdgpu_buffer_rsrc_t r_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab_sc), 0, tab_sc ? tab_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab_sh), 0, tab_sh ? tab_bytes : 0u, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < EpiCfg<T>::EQ; ++q) {
+        r.e_pre[q] = __builtin_amdgcn_raw_buffer_load_b128(r_pre, r.evoff[q], 0, 0);
+        r.e_x[q] = __builtin_amdgcn_raw_buffer_load_b128(r_x, r.evoff[q], 0, 0);
+        r.e_post[q] = __builtin_amdgcn_raw_buffer_load_b128(r_post, r.evoff[q], 0, 0);
+    }
+    const int tb = (n0 + (lane % EpiCfg<T>::NC) * 8) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        r.t_sc[h] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_sc, tb + 16 * h, 0, 0));
+        r.t_sh[h] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_sh, tb + 16 * h, 0, 0));
+    }
+}
+
+// Call after a workgroup barrier that follows the last LDS read of the main loop (the wave images
+// overlay the operand images).  stats_row = this wave's row of the statistics array (< 0: the wave lies
+// entirely outside the tensor and owns no row); ragged = the wave
+// may own rows outside the tensor (their statistics count as zeros).
+template <typename T>
+__device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, const f32x4_t (&acc)[T::FN][T::FM],
+                                           const combat_conv_args &a, unsigned dst_bytes, int lane, int wid, int n0,
+                                           long stats_row, bool ragged) {
+    constexpr int NC = EpiCfg<T>::NC, EQ = EpiCfg<T>::EQ, EPW = EpiCfg<T>::EPW;
+    const int fr = lane & 15, fq = lane >> 4, ec = lane % NC, K = a.K;
+    const bool kind2 = a.stats_kind == 2;
+    const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst ? dst_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc(a.act_dst, 0, a.act_dst ? dst_bytes : 0u, 0x00020000);
+    float *ep = reinterpret_cast<float *>(smem) + wid * EPW;
+#pragma unroll
+    for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j)
+            *reinterpret_cast<f32x4_t *>(ep + (j * 16 + fr) * T::EPS + i * 16 + fq * 4) = acc[i][j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS accesses execute in order
+
+    const bool has_mask = a.mask_x != nullptr, has_scale = a.mask_scale != nullptr, has_act = a.act_dst != nullptr;
+    const bool mul_scale = a.mask_mul_scale != 0;
+    const bool plain_test = !has_scale || a.mask_activated;   // kept-test on mask_x itself
+    const int n = n0 + ec * 8;
+    float bias8[8], msc[8], msh[8], hrs[8], hmn[8], tsc[8], tsh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bias8[e] = hrs[e] = hmn[e] = 0.f;
+        tsc[e] = er.t_sc[e >> 2][e & 3];   // mask tables or activation-output tables
+        tsh[e] = er.t_sh[e >> 2][e & 3];
+        msc[e] = plain_test ? 1.f : tsc[e];
+        msh[e] = plain_test ? 0.f : tsh[e];
+    }
+    if (a.bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
+    if (kind2) {
+        load8f(a.xh_rstd + n, hrs);
+        load8f(a.xh_mean + n, hmn);
+    }
+    float mfac[8];   // factor of a kept element: the scale (BatchNorm backward) or 1
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mfac[e] = mul_scale ? tsc[e] : 1.f;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    u32x4_t packed[EQ], packed_act[EQ];
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) {
+        const int r = (q * 64 + lane) / NC;
+        float v[8], t[8], xm[8];
+        load8f(ep + r * T::EPS + ec * 8, v);
+        unpack8v(er.e_pre[q], t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias8[e] + t[e];
+        if (has_mask) {
+            unpack8v(er.e_x[q], xm);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)   // msc = 1, msh = 0 without a table
+                v[e] *= fmaf(xm[e], msc[e], msh[e]) > 0.f ? mfac[e] : mfac[e] * a.mask_slope;
+        }
+        unpack8v(er.e_post[q], t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += t[e];
+        packed[q] = pack8v(v);
+        if (has_act) {   // the next layer's (eval BatchNorm + ReLU) prologue, applied to the stored value
+            float y[8];
+            unpack8v(packed[q], y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float qa = fmaf(y[e], tsc[e], tsh[e]);
+                y[e] = qa > 0.f ? qa : qa * a.act_slope;
+            }
+            packed_act[q] = pack8v(y);
+        }
+        if (a.stats_kind) {
+            float vr[8];
+            unpack8v(packed[q], vr);
+            if (ragged && er.evoff[q] == kDmaOob) {   // rows beyond the last image count as zeros
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vr[e] = 0.f;
+            }
+            if (kind2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += vr[e];
+                    s2[e] = fmaf(vr[e], (xm[e] - hmn[e]) * hrs[e], s2[e]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += vr[e];
+                    s2[e] = fmaf(vr[e], vr[e], s2[e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed[q], r_dst, er.evoff[q], 0, 0);
+    if (has_act) {
+#pragma unroll
+        for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed_act[q], r_act, er.evoff[q], 0, 0);
+    }
+    if (a.stats_kind && stats_row >= 0) {
+        // one statistics row per wave (32 pixels).  Lanes with equal chunk differ by multiples of NC:
+        // one pass through the wave's LDS image ([lane][16] partial sums; lane -> (chunk, value pair))
+        // instead of log2(64 / NC) dependent cross-lane shuffles of 16 values each.
+        float *sp = ep + lane * 20;   // 16 values + pad: 80-byte pitch keeps the 16-byte stores conflict-free
+        *reinterpret_cast<f32x4_t *>(sp) = f32x4_t{s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4_t *>(sp + 4) = f32x4_t{s1[4], s1[5], s1[6], s1[7]};
+        *reinterpret_cast<f32x4_t *>(sp + 8) = f32x4_t{s2[0], s2[1], s2[2], s2[3]};
+        *reinterpret_cast<f32x4_t *>(sp + 12) = f32x4_t{s2[4], s2[5], s2[6], s2[7]};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // NC chunks x 16 values = NC * 16 sums; lane handles chunk (lane % NC), values vg .. vg + VPL - 1
+        constexpr int VPL = NC * 16 / 64;            // values per lane (2 or 4)
+        const int vg = (lane / NC) * VPL;
+        float tot[VPL];
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) tot[u] = 0.f;
+#pragma unroll
+        for (int src = 0; src < 64 / NC; ++src) {
+            const float *rp = ep + (src * NC + ec) * 20 + vg;
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) tot[u] += rp[u];
+        }
+        // value index v: 0..7 -> sum, 8..15 -> second moment, of channel n + (v & 7)
+        float *orow = a.stats + ((size_t)stats_row * 2 + (vg >> 3)) * K + n + (vg & 7);
+#pragma unroll
+        for (int u = 0; u < VPL; ++u) orow[u] = tot[u];
+    }
+}

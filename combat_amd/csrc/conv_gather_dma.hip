@@ -1,0 +1,295 @@
+// Strided / 1x1 / 3x3 convolutions (forward and input-gradient) WITHOUT an input prologue as a gather-GEMM
+// whose operands are both moved global -> LDS by the DMA path.
+//
+// conv_gemm.hip stages its operands through registers (it has to: the prologue touches every element)
+// with one 64-deep step of prefetch, and at the one or two workgroups per CU these layers give it, a
+// step costs a full global-load round trip (~1.2 us).  Prologue-free launches (eval-mode forwards whose
+// producer wrote the activation, every input-gradient pass, train-mode forwards over a materialised
+// activation) need no VALU work on the way in: here a reduction step (filter tap, 64-channel chunk) is
+//   * 128 gathered pixel rows x 128 B: one 16-byte DMA per lane with its own source address -- stride,
+//     padding and the transposed addressing of the input gradient live in that address; rows whose tap
+//     falls outside the image use an out-of-range buffer offset, which lands in LDS as zeros;
+//   * BN weight rows x 128 B;
+// into a three-stage LDS ring, two steps ahead of the MFMAs; one counted s_waitcnt vmcnt + s_barrier
+// per step.  LDS rows are unpadded (a DMA instruction writes 64 lanes x 16 B contiguously); the eight
+// 16-byte slots of a row are rotated by (row & 6), which keeps ds_read_b128 fragment reads conflict
+// free.  Stride-2 input gradients walk destination pixels parity-class-major (as conv_gemm.hip), so a
+// tile's pixels share their 1, 2 or 4 reachable taps and the others are skipped.
+// The epilogue is the shared DMA-kernel epilogue (conv_dma_epilogue.hpp).
+#include "conv_dma_epilogue.hpp"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+struct GatherParams {
+    combat_conv_args a;
+    int M, PQ, ntaps, cpt;       // dst pixels, P*Q, R*S, 64-channel chunks per tap
+    int tiles_m, tiles_n;
+    int psplit, mq;              // parity-class-major pixel order (stride-2 dgrad), pixels per class
+    int s_shift;
+    unsigned src_bytes, w_bytes, dst_bytes;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm_lgkm0_bar() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int BN>
+__device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
+    constexpr int BM = 128, NS = 3;
+    using T = TileCfg<BM, BN, 4>;           // four waves along the pixels: a wave owns 32 pixels x all BN channels
+    using EC = EpiCfg<T>;
+    constexpr int WPW = BN / 32;            // weight DMA pieces per wave and step
+    constexpr int PBYTES = BM * 128, WBYTES = BN * 128, SBYTES = PBYTES + WBYTES;
+    constexpr int NDMA = 4 + WPW;           // DMA instructions per wave and step
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const combat_conv_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tile_m, tile_n;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = swz % p.tiles_n;
+        tile_m = swz / p.tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int C = a.C, H = a.H, W = a.W;
+
+    // parity-class-major pixel order (psplit): class of this tile, its reachable taps (4 bits each)
+    int pcls = 0, taplist = 0, ntap = p.ntaps;
+    if (p.psplit) {
+        pcls = m0 / p.mq;
+        const int py = pcls >> 1, px = pcls & 1;   // tap r is reachable iff (oy + pad - r) is even
+        ntap = 0;
+        for (int r = (py + a.pad) & 1; r < a.R; r += 2)
+            for (int sx = (px + a.pad) & 1; sx < a.S; sx += 2) taplist |= (r * a.S + sx) << (4 * ntap++);
+    }
+    auto decode = [&](int m, int &img, int &oy, int &ox) {
+        if (p.psplit) {
+            const int rem = m - pcls * p.mq, q4 = p.PQ >> 2, hq = a.Q >> 1;
+            img = rem / q4;
+            const int r2 = rem - img * q4, yy = r2 / hq;
+            oy = 2 * yy + (pcls >> 1);
+            ox = 2 * (r2 - yy * hq) + (pcls & 1);
+        } else {
+            img = m / p.PQ;
+            const int rem = m - img * p.PQ;
+            oy = rem / a.Q;
+            ox = rem - oy * a.Q;
+        }
+    };
+
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
+
+    // ---- this lane's four gathered rows (one per pixel DMA piece): image base, tap origin, channel chunk
+    int g_base[4], g_by[4], g_bx[4], g_ch[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
+        const int m = m0 + row;
+        g_ch[j] = ((slot - (row & 6)) & 7) * 16;        // bytes inside the 64-channel chunk
+        if (m < p.M) {
+            int img, oy, ox;
+            decode(m, img, oy, ox);
+            g_base[j] = img * H * W;
+            g_by[j] = a.mode == 0 ? oy * a.stride - a.pad : oy + a.pad;
+            g_bx[j] = a.mode == 0 ? ox * a.stride - a.pad : ox + a.pad;
+        } else {
+            g_base[j] = -1;
+            g_by[j] = g_bx[j] = 0;
+        }
+        asm volatile("" : "+v"(g_base[j]), "+v"(g_by[j]), "+v"(g_bx[j]), "+v"(g_ch[j]));
+    }
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int n = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
+        wvoff[j] = (unsigned)(((n0 + n) * a.kpad + ((slot - (n & 6)) & 7) * 8) * 2);
+    }
+    // reduction step g -> (filter tap, channel chunk); its operands go to ring stage `stage`
+    auto issue = [&](int g, auto stage_tag) __attribute__((always_inline)) {
+        constexpr int sbase = decltype(stage_tag)::value * SBYTES;
+        const int j_ = g / p.cpt, cc = g - j_ * p.cpt;
+        const int tap = p.psplit ? (taplist >> (4 * j_)) & 15 : j_;
+        const int r = (a.S == 3) ? ((tap * 11) >> 5) : tap, s = tap - r * a.S;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int iy, ix;
+            bool v = g_base[j] >= 0;
+            if (a.mode == 0) {
+                iy = g_by[j] + r;
+                ix = g_bx[j] + s;
+                v = v && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            } else {
+                const int ty = g_by[j] - r, tx = g_bx[j] - s;
+                v = v && ty >= 0 && tx >= 0 && (((ty | tx) & (a.stride - 1)) == 0);
+                iy = ty >> p.s_shift;
+                ix = tx >> p.s_shift;
+                v = v && iy < H && ix < W;
+            }
+            const unsigned off = v ? (unsigned)(((g_base[j] + iy * W + ix) * C + cc * 64) * 2 + g_ch[j]) : kDmaOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(smem + sbase + (wid + 4 * j) * 1024), 16, off, 0, 0, 0);
+        }
+        const int soff = (tap * C + cc * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(smem + sbase + PBYTES + (wid + 4 * j) * 1024), 16,
+                                                     wvoff[j], soff, 0, 0);
+    };
+
+    // ---- fragment read offsets: 16 consecutive rows from a multiple of 16 -> rotation key = lane & 6
+    int fa[2];
+    {
+        const int row = lane & 15, s0 = ((lane >> 4) + (row & 6)) & 7;
+        fa[0] = row * 128 + s0 * 16;
+        fa[1] = row * 128 + (s0 ^ 4) * 16;
+    }
+    f32x4_t acc[T::FN][T::FM];
+#pragma unroll
+    for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](auto stage_tag) __attribute__((always_inline)) {
+        const unsigned char *pb = smem + decltype(stage_tag)::value * SBYTES + wid * 32 * 128;
+        const unsigned char *wb = smem + decltype(stage_tag)::value * SBYTES + PBYTES;
+        bf16x8_t fp[2][T::FM], fw[2][T::FN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int j = 0; j < T::FM; ++j) fp[ks][j] = *reinterpret_cast<const bf16x8_t *>(pb + fa[ks] + j * 2048);
+#pragma unroll
+            for (int i = 0; i < T::FN; ++i) fw[ks][i] = *reinterpret_cast<const bf16x8_t *>(wb + fa[ks] + i * 2048);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i], fp[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- fused epilogue operands: fetched PF steps before the end
+    EpiRegs<T> epi;
+    epi_init<T>(epi, lane, wid, n0, [&](int row) -> long {
+        const int m = m0 + row;
+        if (m >= p.M) return -1;
+        if (!p.psplit) return (long)m * a.K;
+        int img, oy, ox;
+        decode(m, img, oy, ox);
+        return (long)((img * a.P + oy) * a.Q + ox) * a.K;
+    });
+
+    // ---- ring of three stages, steps issued two ahead; unrolled over the stages so that every LDS
+    // address is "register + immediate".  A launch with zero reachable steps (1x1 stride-2 input gradient,
+    // odd pixel classes) still runs the epilogue on zero accumulators.
+    using std::integral_constant;
+    const int nsteps = ntap * p.cpt;
+    constexpr int PF = 3;                       // epilogue fetch this many steps before the end
+    if (nsteps > 0) issue(0, integral_constant<int, 0>{});
+    if (nsteps > 1) issue(1, integral_constant<int, 1>{});
+    if (nsteps <= PF) epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
+    if (nsteps > 1 && nsteps > PF) wait_vm_lgkm0_bar<NDMA>(); else wait_vm_lgkm0_bar<0>();
+    bool fetched = nsteps <= PF;
+    auto body = [&](auto stage_tag, int g) __attribute__((always_inline)) {
+        constexpr int stage = decltype(stage_tag)::value, nstage = (stage + 2) % NS;
+        const bool ahead = g + 2 < nsteps;
+        if (ahead) issue(g + 2, integral_constant<int, nstage>{});
+        const bool fetch_now = !fetched && g + PF >= nsteps;
+        if (fetch_now) {
+            epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
+            fetched = true;
+        }
+        compute(integral_constant<int, stage>{});
+        // step g + 1 must have landed; younger: step g + 2 (if issued) and, if issued after step g + 1's
+        // operands, the epilogue fetches.  Keep it simple and exact: drain everything whenever the
+        // epilogue fetch is in flight (at most PF waits per launch).
+        if (ahead && !fetched) wait_vm_lgkm0_bar<NDMA>(); else wait_vm_lgkm0_bar<0>();
+    };
+    for (int g = 0; g < nsteps; g += NS) {
+        body(integral_constant<int, 0>{}, g);
+        if (g + 1 < nsteps) body(integral_constant<int, 1>{}, g + 1);
+        if (g + 2 < nsteps) body(integral_constant<int, 2>{}, g + 2);
+    }
+    (void)EC::NPF;
+    epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
+                  m0 + BM > p.M);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_gather_dma_kernel(const GatherParams p) { conv_gather_dma_body<BN>(p); }
+
+bool psplit_ok(const combat_conv_args &a) {
+    return a.mode == 1 && a.stride == 2 && (a.P & 1) == 0 && (a.Q & 1) == 0 &&
+           (a.stats_kind == 0 || a.mask_group_stride == 0);
+}
+
+template <int BN>
+int launch(const combat_conv_args *a, hipStream_t st) {
+    GatherParams p;
+    p.a = *a;
+    p.PQ = a->P * a->Q;
+    p.M = a->N * p.PQ;
+    p.ntaps = a->R * a->S;
+    p.cpt = a->C / 64;
+    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_n = a->K / BN;
+    p.psplit = psplit_ok(*a) && (p.M / 4) % 128 == 0;
+    p.mq = p.M / 4;
+    p.s_shift = a->stride == 2 ? 1 : 0;
+    p.src_bytes = (unsigned)((long)a->N * a->H * a->W * a->C * 2);
+    p.w_bytes = (unsigned)((long)a->rows_pad * a->kpad * 2);
+    p.dst_bytes = (unsigned)((long)p.M * a->K * 2);
+    constexpr int stage = 3 * (128 * 128 + BN * 128);
+    constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
+    constexpr int smem = stage > ep ? stage : ep;
+    auto kern = conv_gather_dma_kernel<BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+}  // namespace
+
+// 0 / BN (64 or 32) this kernel would use for these args
+int conv_gather_dma_bn(const combat_conv_args *a) {
+    if (a->pro_scale || a->pro_act || a->tanh_out) return 0;
+    if (a->mask_x && (a->mask_group_stride != 0 || a->act_dst)) return 0;
+    if (a->R != a->S || (a->R != 1 && a->R != 3) || (a->stride != 1 && a->stride != 2)) return 0;
+    if (a->C < 64 || (a->C & 63) || a->kpad < a->R * a->S * a->C) return 0;
+    const long big = 0x40000000L;
+    if ((long)a->N * a->H * a->W * a->C * 2 >= big || (long)a->rows_pad * a->kpad * 2 >= big ||
+        (long)a->N * a->P * a->Q * a->K * 2 >= big)
+        return 0;
+    const long tiles_m = ((long)a->N * a->P * a->Q + 127) / 128;
+    if (a->K % 64 == 0 && tiles_m * (a->K / 64) >= 192) return 64;
+    if (a->K % 32 == 0) return 32;
+    return a->K % 64 == 0 ? 64 : 0;
+}
+
+bool conv_gather_dma_parity_split(const combat_conv_args *a) {
+    return psplit_ok(*a) && ((long)a->N * a->P * a->Q / 4) % 128 == 0;
+}
+
+int conv_gather_dma_launch(const combat_conv_args *a, hipStream_t st) {
+    const int bn = conv_gather_dma_bn(a);
+    if (bn == 64) return launch<64>(a, st);
+    if (bn == 32) return launch<32>(a, st);
+    return COMBAT_EINVAL;
+}

@@ -117,13 +117,15 @@ class AlternatedStep:
         self.k1 = torch.zeros(2, 3, dtype=f32, device=dev)      # sigma_c, sigma_g kernels
         self.transforms = PostTensorTransform(opt)
         self.acc = torch.zeros(8, dtype=torch.float64, device=dev)  # running sums for logging
+        self.acc_side = torch.zeros((), dtype=torch.float64, device=dev)   # detector hits (counted on the second stream)
+        self._side = None
         self._host = None
         self.steps_done = 0
         self._reducers = {}
         self._sets: Dict[int, dict] = {}
 
     # ------------------------------------------------------------------ buffers per batch size
-    _PER_N = ("inputs", "cat_src", "bd", "d_bd", "mse", "tab_f", "tab_i", "h_tab_f", "h_tab_i", "h_k1", "h_targets",
+    _PER_N = ("inputs", "cat_src", "bd", "d_bd", "d_bd2", "mse", "tab_f", "tab_i", "h_tab_f", "h_tab_i", "h_k1", "h_targets",
               "d_targets", "sC_train", "sC_eval", "sC_bd", "sK_eval", "sK_bd", "sG", "sF", "pl", "_targets_of",
               "_gen_small")
 
@@ -144,6 +146,7 @@ class AlternatedStep:
         self.cat_src = torch.zeros(2 * n, 3, hw, hw, dtype=f32, device=dev)   # [inputs ; poisoned images]
         self.bd = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)
         self.d_bd = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)
+        self.d_bd2 = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)   # clean-model share (second stream)
         self.mse = torch.empty(3 * n, dtype=f32, device=dev)   # per (image, channel)
         # one host->device table per step: [5 aug tables | index_small | index_total | k1 x2]
         self.tab_f = torch.zeros(5, n, 4, dtype=f32, device=dev)
@@ -181,6 +184,11 @@ class AlternatedStep:
         self._targets_of = {"C.train": (self.sC_train, eC, (2,), None), "C.eval": (self.sC_eval, eC, (0, 1), None),
                             "K.eval": (self.sK_eval, eK, (0, 0), 1)}
         self._gen_small: Dict[int, tuple] = {}
+
+    def _side_stream(self) -> torch.cuda.Stream:
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        return self._side
 
     def _small(self, nbk: int):
         """Buffers of a poisoned sub-batch bucket: fp32 images, their generator outputs, c8 scratch."""
@@ -246,6 +254,37 @@ class AlternatedStep:
         pl["G_f"].run(prof)
         noise = eG.output(self.sG)
 
+        # ---- fork.  Everything Phase G does with the clean model and the detector depends only on the
+        # generator forward above -- not on Phase C -- so that chain (trigger, two augmentations, the
+        # detector, clean-model forward + input-gradient backward: ~1.5 ms of launches that individually
+        # leave most of the chip idle) runs on a second stream underneath Phase C.  It owns the clean
+        # model's and the detector's engines and the buffers bd / mse / d_bd2; main waits for `ev_bd`
+        # before it reads the poisoned images and for `ev_side` before the generator backward.
+        side = self._side_stream()
+        ev_fork = torch.cuda.Event()
+        ev_fork.record()
+        side.wait_event(ev_fork)
+        xK, xC = eK.input(self.sK_eval), eC.input(self.sC_eval)     # [2n, hw, hw, 8]: metric half, loss half
+        bd_ptr = self.bd.data_ptr()
+        with torch.cuda.stream(side):
+            s2 = side.cuda_stream
+            ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, bd_ptr, None,
+                                             self.mse.data_ptr(), s2), "trigger G")            # :224-226
+            ev_bd = torch.cuda.Event()
+            ev_bd.record()
+            ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[1], n, hw, xK.data_ptr(), None, s2), "augment 1")  # :214
+            ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[4], n, hw, xK[n:].data_ptr(), None, s2), "augment 4")
+            pl["K_eval_f"].run(prof)               # :214 (metric half) + :250-251 (loss half)
+            pl["K_bd_b"].run(prof)
+            ops.check(lib.combat_augment_bwd(self.sK_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[4], n, hw,
+                                             self.d_bd2.data_ptr(), 0, s2), "augment 4 bwd")
+            if eF is not None:                 # :245-247 metric only
+                ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), s2), "dct")
+                pl["F_f"].run(prof)
+                self.acc_side += (self.sF.bufs["logits"].argmax(1) == 1).sum()
+            ev_side = torch.cuda.Event()
+            ev_side.record()
+
         # ================= Phase C (train_generator.py:175-212) =================
         if nb:
             nbk = min(bucket(nb), n)
@@ -262,28 +301,17 @@ class AlternatedStep:
         eC.fp.sgd_step(float(lr_c if lr_c is not None else opt.lr_C), grad_scale=1.0 / self.world)
         eC.mark_weights_dirty()
         eC.refresh()                       # re-pack bf16 operands, fold the new running stats
-        xK, xC = eK.input(self.sK_eval), eC.input(self.sC_eval)     # [2n, hw, hw, 8]: metric half, loss half
-        ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[1], n, hw, xK.data_ptr(), None, st), "augment 1")  # :214
 
-        # ================= Phase G (train_generator.py:216-255; its generator forward ran above) =================
-        ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.bd.data_ptr(), None,
-                                         self.mse.data_ptr(), st), "trigger G")
-        bd_ptr = self.bd.data_ptr()
+        # ================= Phase G (train_generator.py:216-255; generator forward and clean-model chain: above) =====
+        torch.cuda.current_stream().wait_event(ev_bd)
         ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, xC.data_ptr(), None, st), "augment 2")   # :227
         ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, xC[n:].data_ptr(), None, st), "augment 3")
         pl["C_eval_f"].run(prof)               # :227 (metric half) + :228, :231 (loss half)
         pl["C_bd_b"].run(prof)
         ops.check(lib.combat_augment_bwd(self.sC_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[3], n, hw,
                                          self.d_bd.data_ptr(), 0, st), "augment 3 bwd")
-        if eF is not None:                 # :245-247 metric only
-            ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), st), "dct")
-            pl["F_f"].run(prof)
-            self.acc[4] += (self.sF.bufs["logits"].argmax(1) == 1).sum()
-        ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[4], n, hw, xK[n:].data_ptr(), None, st), "augment 4")
-        pl["K_eval_f"].run(prof)               # :214 (metric half) + :250-251 (loss half)
-        pl["K_bd_b"].run(prof)
-        ops.check(lib.combat_augment_bwd(self.sK_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[4], n, hw,
-                                         self.d_bd.data_ptr(), 1, st), "augment 4 bwd")
+        torch.cuda.current_stream().wait_event(ev_side)     # ---- join
+        self.d_bd += self.d_bd2
         l2_scale = float(opt.L2_weight) / float(n * 3 * hw * hw)          # :234, :253
         ops.check(lib.combat_trigger_bwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.d_bd.data_ptr(), bd_ptr,
                                          l2_scale, 1, self.sG.buf("g.z", (n, hw, hw, 8)).data_ptr(), st), "trigger bwd")
@@ -344,7 +372,7 @@ class AlternatedStep:
         w_cm = float(self.opt.clean_model_weight) or 1.0
         out = {"samples": total, "loss_c_sum": 0.0, "loss_ce_sum": 0.0, "clean_model_loss_sum": 0.0,
                "loss_l2_sum": float(acc[0]), "loss_grad_l2_sum": float(acc[1]), "clean_correct": 0, "bd_correct": 0,
-               "f_correct": int(acc[4]), "clean_model_correct": 0, "clean_model_bd_ba": 0, "clean_model_bd_asr": 0,
+               "f_correct": int(self.acc_side.cpu()), "clean_model_correct": 0, "clean_model_bd_ba": 0, "clean_model_bd_asr": 0,
                "train_correct": 0}
         for sCt, sCe, sKe in self._slot_sets():
             cC, cE, kE = self.eC.head_bufs(sCt), self.eC.head_bufs(sCe), self.eK.head_bufs(sKe)
@@ -363,6 +391,7 @@ class AlternatedStep:
 
     def reset_metrics(self) -> None:
         self.acc.zero_()
+        self.acc_side.zero_()
         for sCt, sCe, sKe in self._slot_sets():
             for eng, slot in ((self.eC, sCt), (self.eC, sCe), (self.eK, sKe)):
                 h = eng.head_bufs(slot)

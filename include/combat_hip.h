@@ -118,6 +118,11 @@ typedef struct combat_conv_args {
  * channels per workgroup (conv3x3_dma.hip) */
 #define COMBAT_TILE_D128x64 10
 #define COMBAT_TILE_D128x32 11   /* skinny layers: twice the workgroups */
+/* every other prologue-free convolution with C % 64 == 0 (strided, 1x1, input gradients): gathered pixel
+ * rows and weight rows by DMA into a three-stage LDS ring (conv_gather_dma.hip) */
+#define COMBAT_TILE_G128x64 12
+#define COMBAT_TILE_G128x32 13
+#define COMBAT_TILE_D256x64 14   /* conv3x3_dma with 256-pixel tiles (eight waves): large layers */
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);
 /* tile the launcher would pick for these args (a->tile honoured) and its stats granule */

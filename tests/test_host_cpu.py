@@ -99,7 +99,10 @@ def test_tile_choice_and_stats_layout_are_host_queries(L):
     a.kpad, a.rows_pad = 4608, 512
     assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_H64x64       # skinny layer: halo 64x64
     a.stride, a.P, a.Q = 2, 2, 2
-    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) in (L.TILE_64x64, L.TILE_64x128)   # strided: gather kernel
+    a.pro_act = 0
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) in (L.TILE_G128x64, L.TILE_G128x32)   # strided, no prologue: DMA gather
+    a.pro_act = 1
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) in (L.TILE_64x64, L.TILE_64x128)      # with a prologue: register-staged gather
 
 
 def test_modules_have_no_cpu_fallback():

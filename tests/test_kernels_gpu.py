@@ -105,6 +105,7 @@ DMA_CASES = [
     (3, 8, 256, 256, 10), (5, 8, 128, 64, 10), (2, 8, 64, 64, 10),      # two images per tile, ragged N
     (9, 4, 512, 512, 10), (8, 4, 128, 256, 10), (3, 4, 64, 64, 10),     # eight images per tile
     (4, 32, 64, 64, 11), (3, 16, 128, 64, 11), (5, 8, 128, 64, 11), (9, 4, 512, 512, 11), (7, 4, 256, 256, 0),  # 32-channel tiles
+    (3, 32, 64, 64, 14), (2, 16, 128, 128, 14), (7, 8, 128, 64, 14), (5, 8, 64, 128, 14),     # 256-pixel tiles, ragged N
 ]
 
 
@@ -333,6 +334,28 @@ def test_conv_stride2_dgrad_parity_classes(ops, n, hw, c, k, r):
     got = nchw(dx)
     assert rel_l2(stats.sum(0).cpu()[0], got.sum((0, 2, 3))) < 1e-4
     assert rel_l2(stats.sum(0).cpu()[1], (got * got).sum((0, 2, 3))) < 1e-4
+
+
+def test_conv_gather_dma_ragged_statistics_rows(ops):
+    """A last tile that reaches beyond the tensor must not write statistics rows it does not own (the
+    array has exactly ceil(M / 32) rows): guard rows after the array stay untouched."""
+    n, hw, c, k = 3, 8, 64, 64          # stride-2 forward: M = 3 * 16 = 48 pixels, one 128-row tile
+    x = torch.randn(n, c, hw, hw, generator=g(70))
+    w, pc = make_conv(ops, k, c, 3, 2, 1, 71)
+    y = torch.empty(n, hw // 2, hw // 2, k, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(x), y, pc, 0, stats_kind=1)
+    from combat_amd._lib import lib
+    import ctypes
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) in (12, 13)
+    rows, _ = ops.conv_stats_layout(a)
+    assert rows == 2
+    stats = torch.full((rows + 6, 2, k), 777.0, device="cuda")
+    a.stats = stats.data_ptr()
+    ops.conv_launch(a)
+    assert bool((stats[rows:] == 777.0).all())
+    yr = nchw(y)
+    assert rel_l2(stats[:rows].sum(0).cpu()[0], yr.sum((0, 2, 3))) < 1e-4
+    assert rel_l2(nchw(y), F.conv2d(rb(x), rb(w), stride=2, padding=1)) < 4e-3
 
 
 def test_conv_dgrad_epilogue_mask_stats(ops):
