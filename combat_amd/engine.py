@@ -37,9 +37,14 @@ class Plan:
         self.calls: List[Tuple] = []
         self._keep: List = []
         self.marks: Dict[int, int] = {}   # call index -> flat-gradient offset complete after that call
+        self.aux: set = set()             # indices of calls that may run on the auxiliary stream
 
-    def add(self, what: str, cfunc, *args) -> None:
+    def add(self, what: str, cfunc, *args, aux: bool = False) -> None:
+        """aux: the call's result is only consumed after the plan (weight gradients: by the optimiser /
+        all-reduce), so it may run on the auxiliary stream beside the calls that follow it."""
         self.calls.append((cfunc, args, what))
+        if aux:
+            self.aux.add(len(self.calls) - 1)
 
     def hold(self, *objs) -> None:
         self._keep.extend(objs)
@@ -55,6 +60,8 @@ class Plan:
         has been enqueued (data-parallel bucketed all-reduce overlapping the rest of the backward)."""
         stream = torch.cuda.current_stream()
         st = stream.cuda_stream
+        aux = _aux_stream(stream.device) if self.aux else None
+        aux_used = False
         for ci, (cfunc, args, what) in enumerate(self.calls):
             if prof is not None and cfunc is lib.combat_conv_gemm:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,16 +69,44 @@ class Plan:
                 rc = cfunc(*args, st)
                 e1.record(stream)
                 prof.append((self.name + "/" + what, args[0]._obj, e0, e1))
+            elif ci in self.aux:
+                # everything enqueued so far (the producers of this call's operands) happens-before it
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                aux.wait_event(ev)
+                rc = cfunc(*args, aux.cuda_stream)
+                aux_used = True
             else:
                 rc = cfunc(*args, st)
             if rc:
                 kind = {-1: "invalid shape/argument", -2: "HIP launch failed"}.get(rc, "status %d" % rc)
                 raise CombatHipError("%s/%s: %s" % (self.name, what, kind))
             if on_mark is not None and ci in self.marks:
+                if aux_used:   # the gradients above the mark include auxiliary-stream results
+                    ev = torch.cuda.Event()
+                    ev.record(aux)
+                    stream.wait_event(ev)
                 on_mark(self.marks[ci])
+        if aux_used:           # join: whoever runs after the plan sees every result
+            ev = torch.cuda.Event()
+            ev.record(aux)
+            stream.wait_event(ev)
 
     def __len__(self):
         return len(self.calls)
+
+
+_AUX_STREAMS: Dict = {}
+
+
+def _aux_stream(device) -> torch.cuda.Stream:
+    """One auxiliary stream per device for plan calls marked aux (weight gradients beside the
+    input-gradient chain)."""
+    s = _AUX_STREAMS.get(device)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _AUX_STREAMS[device] = s
+    return s
 
 
 class Slot:
@@ -209,7 +244,7 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
     ws = _wgrad_workspace(src.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     plan.hold(a, src, dy, dw, pro, ws)
-    plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a))
+    plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a), aux=True)
 
 
 _WGRAD_WS: Dict = {}
