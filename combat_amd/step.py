@@ -126,7 +126,7 @@ class AlternatedStep:
 
     # ------------------------------------------------------------------ buffers per batch size
     _PER_N = ("inputs", "cat_src", "bd", "d_bd", "d_bd2", "mse", "tab_f", "tab_i", "h_tab_f", "h_tab_i", "h_k1", "h_targets",
-              "d_targets", "sC_train", "sC_eval", "sC_bd", "sK_eval", "sK_bd", "sG", "sF", "pl", "_targets_of",
+              "d_targets", "sC_train", "sC_eval", "sC_met", "sC_bd", "sK_eval", "sK_bd", "sG", "sF", "pl", "_targets_of",
               "_gen_small")
 
     def _setup(self, n: int):
@@ -157,31 +157,35 @@ class AlternatedStep:
         self.h_targets = torch.zeros(3, n, dtype=torch.int64).pin_memory()    # targets, bd_targets, total_targets
         self.d_targets = torch.zeros(3, n, dtype=torch.int64, device=dev)
         eC, eK, eG = self.eC, self.eK, self.eG
-        # The eval-mode forwards of one network are independent per sample, so the metric-only forward
-        # and the differentiated one run as ONE 2n-image batch [aug(inputs) ; aug(inputs_bd)]
-        # (train_generator.py:227+228 for netC, :214+250 for clean_model -- clean_model is frozen and
-        # :214 reads only `inputs`, so running it in Phase G changes nothing); the backward covers
-        # the triggered half only, through a view slot.
+        # The eval-mode forwards of one network are independent per sample.  clean_model (off the critical
+        # path, second stream): the metric-only forward and the differentiated one run as ONE 2n-image batch
+        # [aug(inputs) ; aug(inputs_bd)] (train_generator.py:214+250 -- clean_model is frozen and :214
+        # reads only `inputs`, so running it in Phase G changes nothing), backward on the triggered half
+        # through a view slot.  netC (:227+228): the differentiated forward is on the critical path and runs
+        # alone; the accuracy-only forward on the clean images goes to the second stream.
         self.sC_train = eC.slot("C.train", n, hw)
-        self.sC_eval = eC.slot("C.eval2", 2 * n, hw)
+        self.sC_eval = eC.slot("C.evalbd", n, hw)      # netC on the triggered images: on the critical path, so on its own
+        self.sC_met = eC.slot("C.metric", n, hw)       # netC on the clean images (accuracy only): second stream
         self.sK_eval = eK.slot("K.eval2", 2 * n, hw)
         self.sG = eG.slot("G", n, hw)
         self.sF = self.eF.slot("F", n, hw) if self.eF is not None else None
         w_cm = float(self.opt.clean_model_weight)
         self.pl = dict(
             C_train_f=eC.forward_plan(self.sC_train, True), C_train_b=eC.backward_train_plan(self.sC_train),
-            C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False, split_head=True),
+            C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False),
+            C_met_f=eC.forward_plan(self.sC_met, False, 1.0, False),
             K_eval_f=eK.forward_plan(self.sK_eval, False, w_cm, True, split_head=True),
             G_f=eG.forward_plan(self.sG), G_b=eG.backward_plan(self.sG),
         )
-        self.sC_bd = self.sC_eval.half_view(n, n, eC.FWD_SHARED)
+        self.sC_bd = self.sC_eval
         self.sK_bd = self.sK_eval.half_view(n, n, eK.FWD_SHARED)
         self.pl["C_bd_b"] = eC.backward_eval_plan(self.sC_bd, 1.0)
         self.pl["K_bd_b"] = eK.backward_eval_plan(self.sK_bd, w_cm)
         if self.sF is not None:
             self.pl["F_f"] = self.eF.forward_plan(self.sF)
         # head targets: (slot, engine, rows of d_targets for [first half, second half], targets2 row)
-        self._targets_of = {"C.train": (self.sC_train, eC, (2,), None), "C.eval": (self.sC_eval, eC, (0, 1), None),
+        self._targets_of = {"C.train": (self.sC_train, eC, (2,), None), "C.eval": (self.sC_eval, eC, (1,), None),
+                            "C.metric": (self.sC_met, eC, (0,), None),
                             "K.eval": (self.sK_eval, eK, (0, 0), 1)}
         self._gen_small: Dict[int, tuple] = {}
 
@@ -264,7 +268,7 @@ class AlternatedStep:
         ev_fork = torch.cuda.Event()
         ev_fork.record()
         side.wait_event(ev_fork)
-        xK, xC = eK.input(self.sK_eval), eC.input(self.sC_eval)     # [2n, hw, hw, 8]: metric half, loss half
+        xK, xC = eK.input(self.sK_eval), eC.input(self.sC_eval)     # [2n, ...]: metric half, loss half / [n, ...]: loss images
         bd_ptr = self.bd.data_ptr()
         with torch.cuda.stream(side):
             s2 = side.cuda_stream
@@ -303,10 +307,18 @@ class AlternatedStep:
         eC.refresh()                       # re-pack bf16 operands, fold the new running stats
 
         # ================= Phase G (train_generator.py:216-255; generator forward and clean-model chain: above) =====
+        ev_c = torch.cuda.Event()              # netC updated and re-packed
+        ev_c.record()
+        with torch.cuda.stream(side):          # :227: accuracy of the updated netC on the clean images (logged only)
+            side.wait_event(ev_c)
+            ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, eC.input(self.sC_met).data_ptr(), None,
+                                             side.cuda_stream), "augment 2")
+            pl["C_met_f"].run(prof)
+            ev_met = torch.cuda.Event()
+            ev_met.record()
         torch.cuda.current_stream().wait_event(ev_bd)
-        ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, xC.data_ptr(), None, st), "augment 2")   # :227
-        ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, xC[n:].data_ptr(), None, st), "augment 3")
-        pl["C_eval_f"].run(prof)               # :227 (metric half) + :228, :231 (loss half)
+        ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, xC.data_ptr(), None, st), "augment 3")
+        pl["C_eval_f"].run(prof)               # :228, :231
         pl["C_bd_b"].run(prof)
         ops.check(lib.combat_augment_bwd(self.sC_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[3], n, hw,
                                          self.d_bd.data_ptr(), 0, st), "augment 3 bwd")
@@ -319,6 +331,7 @@ class AlternatedStep:
         eG.fp.sgd_step(float(lr_g if lr_g is not None else opt.lr_G), grad_scale=1.0 / self.world)
         eG.mark_weights_dirty()
         # ---- logged-only terms (:234-243)
+        torch.cuda.current_stream().wait_event(ev_met)   # the next step's Phase C rewrites netC's operands
         self.acc[0] += self.mse.sum() / float(n * 3 * hw * hw)
         self.acc[1] += self._grad_l2(self.inputs, self.bd)
         self.acc[7] += n
@@ -359,7 +372,7 @@ class AlternatedStep:
     # ------------------------------------------------------------------ metrics
     def _slot_sets(self):
         """(sC_train, sC_eval, sK_eval) of every batch size seen so far."""
-        names = ("sC_train", "sC_eval", "sK_eval")
+        names = ("sC_train", "sC_eval", "sK_eval", "sC_met")
         out = [tuple(getattr(self, k) for k in names)] if self.N else []
         out += [tuple(d[k] for k in names) for n, d in self._sets.items() if n != self.N]
         return out
@@ -374,12 +387,12 @@ class AlternatedStep:
                "loss_l2_sum": float(acc[0]), "loss_grad_l2_sum": float(acc[1]), "clean_correct": 0, "bd_correct": 0,
                "f_correct": int(self.acc_side.cpu()), "clean_model_correct": 0, "clean_model_bd_ba": 0, "clean_model_bd_asr": 0,
                "train_correct": 0}
-        for sCt, sCe, sKe in self._slot_sets():
+        for sCt, sCe, sKe, sCm in self._slot_sets():
             cC, cE, kE = self.eC.head_bufs(sCt), self.eC.head_bufs(sCe), self.eK.head_bufs(sKe)
             out["loss_c_sum"] += float(cC["loss"])
             out["loss_ce_sum"] += float(cE["loss"])
             out["clean_model_loss_sum"] += float(kE["loss"]) / w_cm
-            out["clean_correct"] += int(sCe.bufs["correct0"][0])
+            out["clean_correct"] += int(self.eC.head_bufs(sCm)["correct"][0])
             out["bd_correct"] += int(cE["correct"][0])
             out["clean_model_correct"] += int(sKe.bufs["correct0"][0])
             out["clean_model_bd_ba"] += int(kE["correct"][0])
@@ -392,8 +405,8 @@ class AlternatedStep:
     def reset_metrics(self) -> None:
         self.acc.zero_()
         self.acc_side.zero_()
-        for sCt, sCe, sKe in self._slot_sets():
-            for eng, slot in ((self.eC, sCt), (self.eC, sCe), (self.eK, sKe)):
+        for sCt, sCe, sKe, sCm in self._slot_sets():
+            for eng, slot in ((self.eC, sCt), (self.eC, sCe), (self.eK, sKe), (self.eC, sCm)):
                 h = eng.head_bufs(slot)
                 h["loss"].zero_()
                 h["correct"].zero_()
