@@ -47,17 +47,27 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const combat_pa
     __bf16 *__restrict__ wd = reinterpret_cast<__bf16 *>(d.wd);
     const int K = d.K, taps = d.taps, creal = d.c_real, C = d.C, Kc = (d.K + 7) & ~7;
     const long nf = (long)d.rows_pad_f * d.kpad_f;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nf; t += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(t / d.kpad_f), k = (int)(t - (long)n * d.kpad_f);
-        const int tap = k / C, c = k - tap * C;
-        float v = 0.f;
-        if (n < K && tap < taps) {
-            int cm = -1;
-            if (c < creal) cm = c;
-            else if (d.dup_hilo && c < 2 * creal) cm = c - creal;
-            if (cm >= 0) v = w[((long)n * taps + tap) * creal + cm];
+    if (creal == C && !d.dup_hilo && d.kpad_f == taps * C) {
+        // forward layout == the master's layout: a streaming fp32 -> bf16 conversion, 8 elements per thread
+        const long nreal = (long)K * d.kpad_f;   // rows >= K are zero padding
+        for (long t8 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; t8 < nf; t8 += (long)gridDim.x * blockDim.x * 8) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (t8 < nreal) load8f(w + t8, v);
+            *reinterpret_cast<uint4 *>(wf + t8) = pack8(v);
         }
-        wf[t] = (__bf16)v;
+    } else {
+        for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < nf; t += (long)gridDim.x * blockDim.x) {
+            const int n = (int)(t / d.kpad_f), k = (int)(t - (long)n * d.kpad_f);
+            const int tap = k / C, c = k - tap * C;
+            float v = 0.f;
+            if (n < K && tap < taps) {
+                int cm = -1;
+                if (c < creal) cm = c;
+                else if (d.dup_hilo && c < 2 * creal) cm = c - creal;
+                if (cm >= 0) v = w[((long)n * taps + tap) * creal + cm];
+            }
+            wf[t] = (__bf16)v;
+        }
     }
     if (!wd) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
