@@ -99,6 +99,8 @@ def poison_tables(targets: torch.Tensor, bd_targets: torch.Tensor, num_bd: int):
 class AlternatedStep:
     """Owns the engines, slots and small device tables of one rank's step."""
 
+    kStage = 4   # pinned staging sets (host steps in flight before it has to wait for the device)
+
     def __init__(self, netC, netG, clean_model, netF, opt, process_group=None):
         self.opt = opt
         self.dev = next(netC.parameters()).device
@@ -125,7 +127,7 @@ class AlternatedStep:
         self._sets: Dict[int, dict] = {}
 
     # ------------------------------------------------------------------ buffers per batch size
-    _PER_N = ("inputs", "cat_src", "bd", "d_bd", "d_bd2", "mse", "tab_f", "tab_i", "h_tab_f", "h_tab_i", "h_k1", "h_targets",
+    _PER_N = ("inputs", "cat_src", "bd", "d_bd", "d_bd2", "mse", "tab_f", "tab_i", "_stage", "_stage_i",
               "d_targets", "sC_train", "sC_eval", "sC_met", "sC_bd", "sK_eval", "sK_bd", "sG", "sF", "pl", "_targets_of",
               "_gen_small")
 
@@ -151,10 +153,15 @@ class AlternatedStep:
         # one host->device table per step: [5 aug tables | index_small | index_total | k1 x2]
         self.tab_f = torch.zeros(5, n, 4, dtype=f32, device=dev)
         self.tab_i = torch.zeros(2, n, dtype=torch.int32, device=dev)
-        self.h_tab_f = torch.zeros(5, n, 4, dtype=f32).pin_memory()
-        self.h_tab_i = torch.zeros(2, n, dtype=torch.int32).pin_memory()
-        self.h_k1 = torch.zeros(2, 3, dtype=f32).pin_memory()
-        self.h_targets = torch.zeros(3, n, dtype=torch.int64).pin_memory()    # targets, bd_targets, total_targets
+        # pinned staging, a ring of kStage sets: the host runs several steps ahead of the device, and an
+        # asynchronous copy reads its pinned source when the DEVICE gets to it -- a set is rewritten only
+        # after the event behind its last copy has completed
+        self._stage = [dict(tab_f=torch.zeros(5, n, 4, dtype=f32).pin_memory(),
+                            tab_i=torch.zeros(2, n, dtype=torch.int32).pin_memory(),
+                            k1=torch.zeros(2, 3, dtype=f32).pin_memory(),
+                            targets=torch.zeros(3, n, dtype=torch.int64).pin_memory(),   # targets, bd_targets, total_targets
+                            done=None) for _ in range(self.kStage)]
+        self._stage_i = 0
         self.d_targets = torch.zeros(3, n, dtype=torch.int64, device=dev)
         eC, eK, eG = self.eC, self.eK, self.eG
         # The eval-mode forwards of one network are independent per sample.  clean_model (off the critical
@@ -219,22 +226,29 @@ class AlternatedStep:
         nb = rnd.num_bd
         # ---- host tables (train_generator.py:181-204: batch order [poisoned, rest of target class, others])
         perm, tot, idx_small, idx_total = poison_tables(targets_cpu, bd_targets_cpu, nb)
-        self.h_targets[0].copy_(targets_cpu)
-        self.h_targets[1].copy_(bd_targets_cpu)
-        self.h_targets[2].copy_(tot)
-        self.h_tab_i[0].copy_(idx_small)
-        self.h_tab_i[1].copy_(idx_total)
+        hs = self._stage[self._stage_i]
+        self._stage_i = (self._stage_i + 1) % self.kStage
+        if hs["done"] is not None:
+            hs["done"].synchronize()       # (only ever waits if the device is kStage steps behind)
+        h_targets, h_tab_i, h_tab_f, h_k1 = hs["targets"], hs["tab_i"], hs["tab_f"], hs["k1"]
+        h_targets[0].copy_(targets_cpu)
+        h_targets[1].copy_(bd_targets_cpu)
+        h_targets[2].copy_(tot)
+        h_tab_i[0].copy_(idx_small)
+        h_tab_i[1].copy_(idx_total)
         aug_ptr = []
         for i, a in enumerate(rnd.aug):
             if a is not None:
-                self.h_tab_f[i].copy_(torch.from_numpy(a))
+                h_tab_f[i].copy_(torch.from_numpy(a))
             aug_ptr.append(self.tab_f[i].data_ptr() if a is not None else None)
-        self.h_k1[0].copy_(torch.from_numpy(trigger.gaussian_kernel1d(rnd.sigma_c, opt.kernel_size)))
-        self.h_k1[1].copy_(torch.from_numpy(trigger.gaussian_kernel1d(rnd.sigma_g, opt.kernel_size)))
-        self.tab_f.copy_(self.h_tab_f, non_blocking=True)
-        self.tab_i.copy_(self.h_tab_i, non_blocking=True)
-        self.k1.copy_(self.h_k1, non_blocking=True)
-        self.d_targets.copy_(self.h_targets, non_blocking=True)
+        h_k1[0].copy_(torch.from_numpy(trigger.gaussian_kernel1d(rnd.sigma_c, opt.kernel_size)))
+        h_k1[1].copy_(torch.from_numpy(trigger.gaussian_kernel1d(rnd.sigma_g, opt.kernel_size)))
+        self.tab_f.copy_(h_tab_f, non_blocking=True)
+        self.tab_i.copy_(h_tab_i, non_blocking=True)
+        self.k1.copy_(h_k1, non_blocking=True)
+        self.d_targets.copy_(h_targets, non_blocking=True)
+        hs["done"] = torch.cuda.Event()
+        hs["done"].record()
         self.inputs.copy_(inputs, non_blocking=True)
         self.cat_src[:n].copy_(self.inputs)
         for name, (slot, eng, rows, t2) in self._targets_of.items():
@@ -257,16 +271,29 @@ class AlternatedStep:
         ops.check(lib.combat_image_to_c8(x_ptr, n, hw, eG.input(self.sG).data_ptr(), st), "c8 G")
         pl["G_f"].run(prof)
         noise = eG.output(self.sG)
+        ev_fork = torch.cuda.Event()           # what the second stream's chain depends on (see the fork below)
+        ev_fork.record()
 
-        # ---- fork.  Everything Phase G does with the clean model and the detector depends only on the
+        # ================= Phase C (train_generator.py:175-212) =================
+        if nb:
+            nbk = min(bucket(nb), n)
+            tochange, noise_small, c8_scratch = self._small(nbk)
+            ops.check(lib.combat_augment_fwd(x_ptr, self.tab_i[0].data_ptr(), None, nbk, hw, c8_scratch.data_ptr(),
+                                             tochange.data_ptr(), st), "gather poisoned")
+            torch.index_select(noise, 0, self.tab_i[0][:nbk], out=noise_small)
+            ops.check(lib.combat_trigger_fwd(tochange.data_ptr(), noise_small.data_ptr(), P_, k1c, rate, nb, hw,
+                                             self.cat_src[n:].data_ptr(), None, None, st), "trigger C")
+        ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(), aug_ptr[0], n, hw,
+                                         eC.input(self.sC_train).data_ptr(), None, st), "augment 0")
+        pl["C_train_f"].run(prof)
+        # ---- fork (enqueued after the surrogate forward so that the main queue is never short of work while the
+        # host feeds the second stream).  Everything Phase G does with the clean model and the detector depends only on the
         # generator forward above -- not on Phase C -- so that chain (trigger, two augmentations, the
         # detector, clean-model forward + input-gradient backward: ~1.5 ms of launches that individually
         # leave most of the chip idle) runs on a second stream underneath Phase C.  It owns the clean
         # model's and the detector's engines and the buffers bd / mse / d_bd2; main waits for `ev_bd`
         # before it reads the poisoned images and for `ev_side` before the generator backward.
         side = self._side_stream()
-        ev_fork = torch.cuda.Event()
-        ev_fork.record()
         side.wait_event(ev_fork)
         xK, xC = eK.input(self.sK_eval), eC.input(self.sC_eval)     # [2n, ...]: metric half, loss half / [n, ...]: loss images
         bd_ptr = self.bd.data_ptr()
@@ -289,18 +316,6 @@ class AlternatedStep:
             ev_side = torch.cuda.Event()
             ev_side.record()
 
-        # ================= Phase C (train_generator.py:175-212) =================
-        if nb:
-            nbk = min(bucket(nb), n)
-            tochange, noise_small, c8_scratch = self._small(nbk)
-            ops.check(lib.combat_augment_fwd(x_ptr, self.tab_i[0].data_ptr(), None, nbk, hw, c8_scratch.data_ptr(),
-                                             tochange.data_ptr(), st), "gather poisoned")
-            torch.index_select(noise, 0, self.tab_i[0][:nbk], out=noise_small)
-            ops.check(lib.combat_trigger_fwd(tochange.data_ptr(), noise_small.data_ptr(), P_, k1c, rate, nb, hw,
-                                             self.cat_src[n:].data_ptr(), None, None, st), "trigger C")
-        ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(), aug_ptr[0], n, hw,
-                                         eC.input(self.sC_train).data_ptr(), None, st), "augment 0")
-        pl["C_train_f"].run(prof)
         self._backward_allreduce(pl["C_train_b"], eC, prof)
         eC.fp.sgd_step(float(lr_c if lr_c is not None else opt.lr_C), grad_scale=1.0 / self.world)
         eC.mark_weights_dirty()
