@@ -31,6 +31,7 @@ class ConvArgs(C.Structure):
         ("add_post", c_vp), ("tanh_out", c_i32),
         ("stats_kind", c_i32), ("stats", c_vp), ("xh_mean", c_vp), ("xh_rstd", c_vp),
         ("act_dst", c_vp), ("act_scale", c_vp), ("act_shift", c_vp), ("act_slope", c_f32),
+        ("workspace", c_vp), ("workspace_bytes", c_i64),
         ("tile", c_i32),
     ]
 
@@ -69,6 +70,7 @@ SIGNATURES = {
     "combat_version": (C.c_char_p, []),
     "combat_abi_version": (C.c_int, []),
     "combat_conv_gemm": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
+    "combat_conv_workspace_bytes": (c_i64, [C.POINTER(ConvArgs)]),
     "combat_conv_pick_tile": (C.c_int, [C.POINTER(ConvArgs)]),
     "combat_conv_stats_granule": (C.c_int, [C.c_int]),
     "combat_conv_stats_layout": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(c_i32), C.POINTER(c_i32)]),

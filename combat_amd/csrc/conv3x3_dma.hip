@@ -299,7 +299,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     // ---- epilogue: accumulators -> this wave's fp32 LDS image (the operand images are dead once every
     // wave has passed the barrier) -> row-major items
     block_barrier();
-    epi_finish<T>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged);
+    epi_finish<T>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged, p.PQ);
     DSTAMP(4);
 }
 
@@ -319,9 +319,7 @@ int geo_tw(const combat_conv_args *a) {
 bool applicable(const combat_conv_args *a, int BN) {
     if (!(a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->P == a->H && a->Q == a->W)) return false;
     if (a->pro_scale || a->pro_act) return false;   // operands go straight to LDS: no prologue
-    // epilogue: per-channel (BatchNorm) tables only -- per-image (InstanceNorm) tables and tanh stay
-    // with the halo kernels
-    if (a->tanh_out || (a->mask_x && a->mask_group_stride != 0)) return false;
+    if (a->tanh_out) return false;   // (stays with the halo kernels)
     if (a->mask_x && a->act_dst) return false;   // one table pair travels with the operand prefetch
     if (a->C < 64 || (a->C & 63) || a->K % BN || a->kpad < 9 * a->C) return false;
     if ((long)a->N * a->H * a->W * a->C * 2 >= (long)kOob) return false;

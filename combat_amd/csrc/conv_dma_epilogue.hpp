@@ -76,7 +76,7 @@ __device__ __forceinline__ void epi_fetch(EpiRegs<T> &r, const combat_conv_args 
 template <typename T>
 __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, const f32x4_t (&acc)[T::FN][T::FM],
                                            const combat_conv_args &a, unsigned dst_bytes, int lane, int wid, int n0,
-                                           long stats_row, bool ragged) {
+                                           long stats_row, bool ragged, int PQ) {
     constexpr int NC = EpiCfg<T>::NC, EQ = EpiCfg<T>::EQ, EPW = EpiCfg<T>::EPW;
     const int fr = lane & 15, fq = lane >> 4, ec = lane % NC, K = a.K;
     const bool kind2 = a.stats_kind == 2;
@@ -93,6 +93,7 @@ __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, 
     const bool has_mask = a.mask_x != nullptr, has_scale = a.mask_scale != nullptr, has_act = a.act_dst != nullptr;
     const bool mul_scale = a.mask_mul_scale != 0;
     const bool plain_test = !has_scale || a.mask_activated;   // kept-test on mask_x itself
+    const bool per_image = has_mask && a.mask_group_stride != 0;
     const int n = n0 + ec * 8;
     float bias8[8], msc[8], msh[8], hrs[8], hmn[8], tsc[8], tsh[8];
 #pragma unroll
@@ -104,7 +105,7 @@ __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, 
         msh[e] = plain_test ? 0.f : tsh[e];
     }
     if (a.bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
-    if (kind2) {
+    if (kind2 && !per_image) {
         load8f(a.xh_rstd + n, hrs);
         load8f(a.xh_mean + n, hmn);
     }
@@ -125,6 +126,23 @@ __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, 
         for (int e = 0; e < 8; ++e) v[e] += bias8[e] + t[e];
         if (has_mask) {
             unpack8v(er.e_x[q], xm);
+            if (per_image && er.evoff[q] != kDmaOob) {   // InstanceNorm: tables of this row's image (L2-resident)
+                const long g = (long)((er.evoff[q] >> 1) / (unsigned)K / (unsigned)PQ) * a.mask_group_stride + n;
+                if (has_scale) {
+                    load8f(a.mask_scale + g, tsc);
+                    load8f(a.mask_shift + g, tsh);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        msc[e] = plain_test ? 1.f : tsc[e];
+                        msh[e] = plain_test ? 0.f : tsh[e];
+                        mfac[e] = mul_scale ? tsc[e] : 1.f;
+                    }
+                }
+                if (kind2) {
+                    load8f(a.xh_rstd + g, hrs);
+                    load8f(a.xh_mean + g, hmn);
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e)   // msc = 1, msh = 0 without a table
                 v[e] *= fmaf(xm[e], msc[e], msh[e]) > 0.f ? mfac[e] : mfac[e] * a.mask_slope;

@@ -29,6 +29,8 @@ struct GatherParams {
     int psplit, mq;              // parity-class-major pixel order (stride-2 dgrad), pixels per class
     int s_shift;
     unsigned src_bytes, w_bytes, dst_bytes;
+    int splits;                  // > 1: the reduction steps of a tile are divided among `splits` workgroups that
+    float *ws;                   //      write fp32 slabs [split][tile][128][BN] here; conv_gather_finish_kernel combines
 };
 
 template <int N>
@@ -38,7 +40,9 @@ __device__ __forceinline__ void wait_vm_lgkm0_bar() {
     asm volatile("" ::: "memory");
 }
 
-template <int BN>
+// FINISH = false: the convolution (whole, or one slab of a split reduction).  FINISH = true: the second
+// launch of a split reduction: sum the slabs into the accumulators and run the fused epilogue.
+template <int BN, bool FINISH>
 __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     constexpr int BM = 128, NS = 3;
     using T = TileCfg<BM, BN, 4>;           // four waves along the pixels: a wave owns 32 pixels x all BN channels
@@ -51,13 +55,15 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int tile_m, tile_n;
+    int tile_m, tile_n, sp, tile;
     {
-        const int nb = gridDim.x, bid = blockIdx.x;
+        const int ntile = p.tiles_m * p.tiles_n;
+        const int nb = ntile, bid = blockIdx.x % ntile;
+        sp = blockIdx.x / ntile;                       // slab of a split reduction (0 otherwise)
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tile_n = swz % p.tiles_n;
-        tile_m = swz / p.tiles_n;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = tile % p.tiles_n;
+        tile_m = tile / p.tiles_n;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int C = a.C, H = a.H, W = a.W;
@@ -194,18 +200,46 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     // address is "register + immediate".  A launch with zero reachable steps (1x1 stride-2 input gradient,
     // odd pixel classes) still runs the epilogue on zero accumulators.
     using std::integral_constant;
-    const int nsteps = ntap * p.cpt;
+    const int fr = lane & 15, fq = lane >> 4;
+    const size_t slab = (size_t)BM * BN;        // floats per (split, tile)
+    if (FINISH) {
+        // ---- second launch of a split reduction: accumulators = sum of the slabs (fragment layout), epilogue
+        epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FM; ++j) {
+                const float *src = p.ws + (size_t)tile * slab + (wid * 32 + j * 16 + fr) * BN + i * 16 + fq * 4;
+                f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < p.splits; ++q)
+                    v += *reinterpret_cast<const f32x4_t *>(src + (size_t)q * p.tiles_m * p.tiles_n * slab);
+                acc[i][j] = v;
+            }
+        epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
+                      m0 + BM > p.M, p.PQ);
+        return;
+    }
+    const int nsteps_all = ntap * p.cpt;
+    int g_lo = 0, nsteps = nsteps_all;
+    if (p.splits > 1) {
+        const int per = (nsteps_all + p.splits - 1) / p.splits;
+        g_lo = sp * per;
+        nsteps = nsteps_all - g_lo < per ? nsteps_all - g_lo : per;
+        if (nsteps < 0) nsteps = 0;
+    }
+    const bool whole = p.splits <= 1;           // this workgroup also runs the epilogue
     constexpr int PF = 3;                       // epilogue fetch this many steps before the end
-    if (nsteps > 0) issue(0, integral_constant<int, 0>{});
-    if (nsteps > 1) issue(1, integral_constant<int, 1>{});
-    if (nsteps <= PF) epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
-    if (nsteps > 1 && nsteps > PF) wait_vm_lgkm0_bar<NDMA>(); else wait_vm_lgkm0_bar<0>();
-    bool fetched = nsteps <= PF;
+    if (nsteps > 0) issue(g_lo, integral_constant<int, 0>{});
+    if (nsteps > 1) issue(g_lo + 1, integral_constant<int, 1>{});
+    if (whole && nsteps <= PF) epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
+    if (nsteps > 1 && (nsteps > PF || !whole)) wait_vm_lgkm0_bar<NDMA>(); else wait_vm_lgkm0_bar<0>();
+    bool fetched = !whole || nsteps <= PF;      // (a slab never fetches: `fetched` then only selects the plain waits)
+    const bool drain = whole;                   // after the epilogue fetch every wait drains the queue
     auto body = [&](auto stage_tag, int g) __attribute__((always_inline)) {
         constexpr int stage = decltype(stage_tag)::value, nstage = (stage + 2) % NS;
         const bool ahead = g + 2 < nsteps;
-        if (ahead) issue(g + 2, integral_constant<int, nstage>{});
-        const bool fetch_now = !fetched && g + PF >= nsteps;
+        if (ahead) issue(g_lo + g + 2, integral_constant<int, nstage>{});
+        const bool fetch_now = whole && !fetched && g + PF >= nsteps;
         if (fetch_now) {
             epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
             fetched = true;
@@ -214,7 +248,7 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         // step g + 1 must have landed; younger: step g + 2 (if issued) and, if issued after step g + 1's
         // operands, the epilogue fetches.  Keep it simple and exact: drain everything whenever the
         // epilogue fetch is in flight (at most PF waits per launch).
-        if (ahead && !fetched) wait_vm_lgkm0_bar<NDMA>(); else wait_vm_lgkm0_bar<0>();
+        if (ahead && !(drain && fetched)) wait_vm_lgkm0_bar<NDMA>(); else wait_vm_lgkm0_bar<0>();
     };
     for (int g = 0; g < nsteps; g += NS) {
         body(integral_constant<int, 0>{}, g);
@@ -222,12 +256,33 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         if (g + 2 < nsteps) body(integral_constant<int, 2>{}, g + 2);
     }
     (void)EC::NPF;
+    if (!whole) {   // this workgroup's slab, straight from the fragments (16 bytes per lane, 64 per row and quad)
+        float *dst = p.ws + ((size_t)sp * p.tiles_m * p.tiles_n + tile) * slab;
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FM; ++j)
+                *reinterpret_cast<f32x4_t *>(dst + (wid * 32 + j * 16 + fr) * BN + i * 16 + fq * 4) = acc[i][j];
+        return;
+    }
     epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
-                  m0 + BM > p.M);
+                  m0 + BM > p.M, p.PQ);
 }
 
 template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_gather_dma_kernel(const GatherParams p) { conv_gather_dma_body<BN>(p); }
+__global__ __launch_bounds__(256, 2) void conv_gather_dma_kernel(const GatherParams p) { conv_gather_dma_body<BN, false>(p); }
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_gather_finish_kernel(const GatherParams p) { conv_gather_dma_body<BN, true>(p); }
+
+// Workgroups per tile for a launch with `tiles` tiles and `nsteps` reduction steps: split the reduction
+// only when the tiles alone leave most of the chip idle (skinny layers: 2x2 / 4x4 feature maps).
+int pick_splits(long tiles, int nsteps) {
+    if (tiles >= 96 || nsteps < 8) return 1;
+    int s = (int)(256 / tiles);
+    if (s > 8) s = 8;
+    if (s > nsteps / 4) s = nsteps / 4;
+    return s < 2 ? 1 : s;
+}
 
 bool psplit_ok(const combat_conv_args &a) {
     return a.mode == 1 && a.stride == 2 && (a.P & 1) == 0 && (a.Q & 1) == 0 &&
@@ -250,27 +305,41 @@ int launch(const combat_conv_args *a, hipStream_t st) {
     p.src_bytes = (unsigned)((long)a->N * a->H * a->W * a->C * 2);
     p.w_bytes = (unsigned)((long)a->rows_pad * a->kpad * 2);
     p.dst_bytes = (unsigned)((long)p.M * a->K * 2);
+    const int nsteps = p.ntaps * p.cpt;
+    p.splits = p.psplit ? 1 : pick_splits((long)p.tiles_m * p.tiles_n, nsteps);
+    const long need = (long)p.splits * p.tiles_m * p.tiles_n * 128 * BN * 4;
+    if (p.splits > 1 && (!a->workspace || a->workspace_bytes < need)) p.splits = 1;
+    p.ws = p.splits > 1 ? reinterpret_cast<float *>(a->workspace) : nullptr;
     constexpr int stage = 3 * (128 * 128 + BN * 128);
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
     constexpr int smem = stage > ep ? stage : ep;
     auto kern = conv_gather_dma_kernel<BN>;
+    auto fin = conv_gather_finish_kernel<BN>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return COMBAT_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    const int tiles = p.tiles_m * p.tiles_n;
+    hipLaunchKernelGGL(kern, dim3(tiles * (p.splits > 1 ? p.splits : 1)), dim3(256), smem, st, p);
     CB_LAUNCH_CHECK();
+    if (p.splits > 1) {
+        hipLaunchKernelGGL(fin, dim3(tiles), dim3(256), ep, st, p);
+        CB_LAUNCH_CHECK();
+    }
     return COMBAT_OK;
 }
 
 }  // namespace
 
+bool conv_gather_dma_parity_split(const combat_conv_args *a);
+
 // 0 / BN (64 or 32) this kernel would use for these args
 int conv_gather_dma_bn(const combat_conv_args *a) {
     if (a->pro_scale || a->pro_act || a->tanh_out) return 0;
-    if (a->mask_x && (a->mask_group_stride != 0 || a->act_dst)) return 0;
+    if (a->mask_x && a->act_dst) return 0;
     if (a->R != a->S || (a->R != 1 && a->R != 3) || (a->stride != 1 && a->stride != 2)) return 0;
     if (a->C < 64 || (a->C & 63) || a->kpad < a->R * a->S * a->C) return 0;
     const long big = 0x40000000L;
@@ -281,6 +350,15 @@ int conv_gather_dma_bn(const combat_conv_args *a) {
     if (a->K % 64 == 0 && tiles_m * (a->K / 64) >= 192) return 64;
     if (a->K % 32 == 0) return 32;
     return a->K % 64 == 0 ? 64 : 0;
+}
+
+// scratch bytes a launch for these args can use (0: none): slabs of a split reduction
+long conv_gather_dma_workspace(const combat_conv_args *a) {
+    const int bn = conv_gather_dma_bn(a);
+    if (!bn || conv_gather_dma_parity_split(a)) return 0;
+    const long tiles = (((long)a->N * a->P * a->Q + 127) / 128) * (a->K / bn);
+    const int s = pick_splits(tiles, a->R * a->S * (a->C / 64));
+    return s > 1 ? (long)s * tiles * 128 * bn * 4 : 0;
 }
 
 bool conv_gather_dma_parity_split(const combat_conv_args *a) {

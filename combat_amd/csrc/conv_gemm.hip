@@ -308,6 +308,9 @@ int launch(const ConvParams &p, hipStream_t st) {
 }
 
 int pick_tile(const combat_conv_args *a) {
+    if (a->tile == 0 && a->workspace && conv_gather_dma_workspace(a) > 0 &&
+        a->workspace_bytes >= conv_gather_dma_workspace(a))   // skinny layer: split reduction beats any single-workgroup tile
+        return conv_gather_dma_bn(a) == 64 ? COMBAT_TILE_G128x64 : COMBAT_TILE_G128x32;
     if (const int halo = conv3x3_pick(a)) return halo;   // 3x3 / stride 1 with the patch held in LDS
     if ((a->tile >= COMBAT_TILE_H256x64 && a->tile < COMBAT_TILE_G128x64) || a->tile == COMBAT_TILE_D256x64)
         return 0;   // a 3x3 tile was forced but does not apply
@@ -328,6 +331,11 @@ int pick_tile(const combat_conv_args *a) {
 }  // namespace
 
 extern "C" int combat_conv_pick_tile(const combat_conv_args *a) { return a ? pick_tile(a) : COMBAT_EINVAL; }
+
+extern "C" int64_t combat_conv_workspace_bytes(const combat_conv_args *a) {
+    if (!a || (a->tile && a->tile != COMBAT_TILE_G128x64 && a->tile != COMBAT_TILE_G128x32)) return 0;
+    return (int64_t)conv_gather_dma_workspace(a);   // (with it, a skinny 3x3 layer is routed to the gather kernel)
+}
 
 extern "C" int combat_conv_stats_granule(int tile) {
     switch (tile) {

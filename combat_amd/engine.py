@@ -38,6 +38,7 @@ class Plan:
         self._keep: List = []
         self.marks: Dict[int, int] = {}   # call index -> flat-gradient offset complete after that call
         self.aux: set = set()             # indices of calls that may run on the auxiliary stream
+        self._ws = None
 
     def add(self, what: str, cfunc, *args, aux: bool = False) -> None:
         """aux: the call's result is only consumed after the plan (weight gradients: by the optimiser /
@@ -48,6 +49,13 @@ class Plan:
 
     def hold(self, *objs) -> None:
         self._keep.extend(objs)
+
+    def workspace(self, device) -> torch.Tensor:
+        """Scratch of this plan's convolutions (split reductions of skinny layers).  Per plan: the calls of
+        one plan run one after the other on one stream, two plans may run concurrently."""
+        if self._ws is None:
+            self._ws = torch.empty(16 << 20, dtype=torch.uint8, device=device)
+        return self._ws
 
     def mark(self, grad_offset: int) -> None:
         """Every gradient at flat offset >= grad_offset is final once the calls recorded so far ran."""
@@ -228,7 +236,7 @@ class FlatParams:
 
 
 def rec_conv(plan: Plan, what: str, src, dst, pc: PackedConv, mode: int, **kw):
-    a = ops.conv_args(src, dst, pc, mode, **kw)
+    a = ops.conv_args(src, dst, pc, mode, workspace=plan.workspace(src.device), **kw)
     plan.hold(a)
     plan.add(what, lib.combat_conv_gemm, ctypes.byref(a))
     return a
@@ -354,7 +362,7 @@ class NetEngine:
         (optionally updating running stats); groups == N: instance statistics."""
         n, p, q, c = dst.shape
         pq, m = p * q, n * p * q
-        a = ops.conv_args(src, dst, pc, 0, **conv_kw)
+        a = ops.conv_args(src, dst, pc, 0, workspace=plan.workspace(src.device), **conv_kw)
         rows, rpi = ops.conv_stats_layout(a)
         fused = (groups == 1) or (rpi > 0)
         st = slot.norm.get(key)
@@ -392,7 +400,7 @@ class NetEngine:
         pq, m = p * q, n * p * q
         groups = st.groups
         mask = Affine(st.scale, st.shift, group_stride, True, slope)
-        a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask)
+        a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask, workspace=plan.workspace(dy.device))
         rows, rpi = ops.conv_stats_layout(a)
         fused = (groups == 1) or (rpi > 0)
         if fused:

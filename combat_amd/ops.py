@@ -91,7 +91,7 @@ class PackedConv:
 def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = None, bias=None, add_pre=None,
               mask_x=None, mask: Optional[Affine] = None, mask_mul_scale=False, add_post=None, tanh_out=False,
               stats_kind=0, stats=None, xh_mean=None, xh_rstd=None, tile=0, act_dst=None,
-              act: Optional[Affine] = None, mask_activated=False) -> ConvArgs:
+              act: Optional[Affine] = None, mask_activated=False, workspace=None) -> ConvArgs:
     """act_dst / act: second output bf16(lrelu(y * act.scale + act.shift)) of the stored value y (the
     next layer's eval-mode BatchNorm + ReLU); dst may then be None.  mask_activated: mask_x is such an
     activation (kept-test mask_x > 0)."""
@@ -121,8 +121,13 @@ def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = No
     a.stats_kind, a.stats = stats_kind, _p(stats)
     a.xh_mean, a.xh_rstd = _p(xh_mean), _p(xh_rstd)
     a.tile = tile
+    if workspace is not None:   # scratch for a split reduction (skinny layers); set before any layout query
+        need = int(lib.combat_conv_workspace_bytes(ctypes.byref(a)))
+        if 0 < need <= workspace.numel() * workspace.element_size():
+            a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     # the struct holds raw pointers: keep every tensor alive as long as the struct is
-    a._keepalive = (src, dst, pc, pro, bias, add_pre, mask_x, mask, add_post, stats, xh_mean, xh_rstd, act_dst, act)
+    a._keepalive = (src, dst, pc, pro, bias, add_pre, mask_x, mask, add_post, stats, xh_mean, xh_rstd, act_dst, act,
+                    workspace)
     return a
 
 

@@ -99,6 +99,11 @@ typedef struct combat_conv_args {
     void *act_dst;
     const float *act_scale, *act_shift;
     float act_slope;
+    /* optional scratch (may be NULL): skinny layers (few tiles, long reductions) divide the reduction among
+       several workgroups per tile, which write fp32 slabs here and are combined by a second launch; needs
+       combat_conv_workspace_bytes(a) bytes, used only by this launch */
+    void *workspace;
+    int64_t workspace_bytes;
     int32_t tile;                /* 0 = auto; else a COMBAT_TILE_* value */
 } combat_conv_args;
 
@@ -125,6 +130,8 @@ typedef struct combat_conv_args {
 #define COMBAT_TILE_D256x64 14   /* conv3x3_dma with 256-pixel tiles (eight waves): large layers */
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);
+/* scratch bytes the launch for these args can use (0: none) */
+int64_t combat_conv_workspace_bytes(const combat_conv_args *a);
 /* tile the launcher would pick for these args (a->tile honoured) and its stats granule */
 int combat_conv_pick_tile(const combat_conv_args *a);
 int combat_conv_stats_granule(int tile);

@@ -336,6 +336,39 @@ def test_conv_stride2_dgrad_parity_classes(ops, n, hw, c, k, r):
     assert rel_l2(stats.sum(0).cpu()[1], (got * got).sum((0, 2, 3))) < 1e-4
 
 
+@pytest.mark.parametrize("n,hw,c,k,r,stride,mode", [(16, 2, 512, 512, 3, 1, 0), (16, 2, 512, 512, 3, 1, 1), (9, 4, 256, 256, 3, 1, 0),
+                                                   (32, 8, 256, 512, 3, 2, 0), (10, 4, 512, 128, 1, 1, 0)])
+def test_conv_split_reduction(ops, n, hw, c, k, r, stride, mode):
+    """Skinny layers (few tiles, long reductions) given a workspace: the reduction steps of a tile are divided
+    among several workgroups, slabs combined by a second launch that runs the fused epilogue."""
+    from combat_amd._lib import lib
+    import ctypes
+    pad = 1 if r == 3 else 0
+    x = torch.randn(n, c, hw, hw, generator=g(80))
+    w, pc = make_conv(ops, k, c, r, stride, pad, 81)
+    p = hw // stride
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    if mode == 0:
+        res = torch.randn(n, k, p, p, generator=g(82))
+        y = torch.empty(n, p, p, k, dtype=bf16, device="cuda")
+        a = ops.conv_args(nhwc(x), y, pc, 0, add_post=nhwc(res), stats_kind=1, workspace=ws)
+        assert a.workspace and lib.combat_conv_pick_tile(ctypes.byref(a)) in (12, 13)
+        rows, _ = ops.conv_stats_layout(a)
+        stats = torch.zeros(rows, 2, k, device="cuda")
+        a.stats = stats.data_ptr()
+        ops.conv_launch(a)
+        ref = F.conv2d(rb(x), rb(w), stride=stride, padding=pad) + rb(res)
+        assert rel_l2(nchw(y), ref) < 4e-3
+        assert rel_l2(stats.sum(0).cpu()[0], nchw(y).sum((0, 2, 3))) < 1e-4
+    else:
+        dy = torch.randn(n, k, p, p, generator=g(83))
+        dx = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+        a = ops.conv_args(nhwc(dy), dx, pc, 1, workspace=ws)
+        assert a.workspace and lib.combat_conv_pick_tile(ctypes.byref(a)) in (12, 13)
+        ops.conv_launch(a)
+        assert rel_l2(nchw(dx), torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), stride=stride, padding=pad)) < 4e-3
+
+
 def test_conv_gather_dma_ragged_statistics_rows(ops):
     """A last tile that reaches beyond the tensor must not write statistics rows it does not own (the
     array has exactly ceil(M / 32) rows): guard rows after the array stay untouched."""
