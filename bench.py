@@ -252,12 +252,18 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
+        # kernel-level numbers: replay with every launch in line on one stream (the timed region above
+        # overlaps three streams, which stretches every kernel it brackets by what runs beside it)
+        from combat_amd.engine import Plan
         prof = []
+        st.serial = Plan.serial = True
         for i in range(args.steps):
             x, t = batches[i % len(batches)]
             st.run(x, t, prof=prof)
         torch.cuda.synchronize()
+        st.serial = Plan.serial = False
         roof = roofline_from(prof)
+        roof["replay"] = "serial (one stream), HIP events around each launch"
         log("instrumented replay done: %s %.1f TFLOP/s" % (roof["kernel"], roof["achieved"]))
     if world > 1:
         torch.distributed.barrier()

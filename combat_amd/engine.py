@@ -32,6 +32,8 @@ def _p(t):
 class Plan:
     """An ordered list of C-ABI calls with pre-marshalled arguments (stream appended at run)."""
 
+    serial = False   # True: auxiliary-stream calls run in line (kernel-level measurements: one kernel at a time)
+
     def __init__(self, name: str):
         self.name = name
         self.calls: List[Tuple] = []
@@ -68,7 +70,7 @@ class Plan:
         has been enqueued (data-parallel bucketed all-reduce overlapping the rest of the backward)."""
         stream = torch.cuda.current_stream()
         st = stream.cuda_stream
-        aux = _aux_stream(stream) if self.aux else None
+        aux = _aux_stream(stream) if self.aux and not Plan.serial else None
         aux_used = False
         for ci, (cfunc, args, what) in enumerate(self.calls):
             if prof is not None and cfunc is lib.combat_conv_gemm:
@@ -77,7 +79,7 @@ class Plan:
                 rc = cfunc(*args, st)
                 e1.record(stream)
                 prof.append((self.name + "/" + what, args[0]._obj, e0, e1))
-            elif ci in self.aux:
+            elif aux is not None and ci in self.aux:
                 # everything enqueued so far (the producers of this call's operands) happens-before it
                 ev = torch.cuda.Event()
                 ev.record(stream)

@@ -99,6 +99,7 @@ def poison_tables(targets: torch.Tensor, bd_targets: torch.Tensor, num_bd: int):
 class AlternatedStep:
     """Owns the engines, slots and small device tables of one rank's step."""
 
+    serial = False   # True: no second stream (bench.py's instrumented replay times one kernel at a time)
     kStage = 4   # pinned staging sets (host steps in flight before it has to wait for the device)
 
     def __init__(self, netC, netG, clean_model, netF, opt, process_group=None):
@@ -197,6 +198,8 @@ class AlternatedStep:
         self._gen_small: Dict[int, tuple] = {}
 
     def _side_stream(self) -> torch.cuda.Stream:
+        if self.serial:            # kernel-level measurements: everything in line on the caller's stream
+            return torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
         return self._side
