@@ -117,19 +117,19 @@ class AlternatedStep:
         dev = self.dev
         self.P = trigger.lowpass_matrix(self.hw, opt.ratio).to(dev)
         self.D = trigger.dct_matrix(self.hw).float().to(dev)
-        self.k1 = torch.zeros(2, 3, dtype=f32, device=dev)      # sigma_c, sigma_g kernels
         self.transforms = PostTensorTransform(opt)
         self.acc = torch.zeros(8, dtype=torch.float64, device=dev)  # running sums for logging
         self.acc_side = torch.zeros((), dtype=torch.float64, device=dev)   # detector hits (counted on the second stream)
         self._side = None
         self._host = None
         self.steps_done = 0
+        self.samples = 0                 # images since the last metric reset
         self._reducers = {}
         self._sets: Dict[int, dict] = {}
 
     # ------------------------------------------------------------------ buffers per batch size
-    _PER_N = ("inputs", "cat_src", "bd", "d_bd", "d_bd2", "mse", "tab_f", "tab_i", "_stage", "_stage_i",
-              "d_targets", "sC_train", "sC_eval", "sC_met", "sC_bd", "sK_eval", "sK_bd", "sG", "sF", "pl", "_targets_of",
+    _PER_N = ("inputs", "cat_src", "bd", "d_bd", "d_bd2", "mse", "tab", "tab_f", "tab_i", "k1", "_stage", "_stage_i",
+              "d_targets", "sC_train", "sC_eval", "sC_met", "sC_bd", "sK_eval", "sK_bd", "sG", "sF", "pl",
               "_gen_small")
 
     def _setup(self, n: int):
@@ -145,25 +145,28 @@ class AlternatedStep:
             self.N = n
             return
         self.N, dev, hw = n, self.dev, self.hw
-        self.inputs = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)
         self.cat_src = torch.zeros(2 * n, 3, hw, hw, dtype=f32, device=dev)   # [inputs ; poisoned images]
+        self.inputs = self.cat_src[:n]
         self.bd = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)
         self.d_bd = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)
         self.d_bd2 = torch.empty(n, 3, hw, hw, dtype=f32, device=dev)   # clean-model share (second stream)
         self.mse = torch.empty(3 * n, dtype=f32, device=dev)   # per (image, channel)
-        # one host->device table per step: [5 aug tables | index_small | index_total | k1 x2]
-        self.tab_f = torch.zeros(5, n, 4, dtype=f32, device=dev)
-        self.tab_i = torch.zeros(2, n, dtype=torch.int32, device=dev)
+        # ONE host->device table per step (one copy instead of a dozen 10-us ones in front of the generator
+        # forward): [5 aug tables | index_small, index_total | blur kernels of sigma_c, sigma_g | label rows].
+        # Label rows: 0 targets, 1 bd_targets, 2 total_targets (re-ordered batch), 3-4 targets twice (the clean
+        # model's 2n batch), 5-6 its second label set (row 6 = bd_targets); the heads' label buffers are
+        # views of these rows.
+        self.tab = torch.zeros(self._table_bytes(n), dtype=torch.uint8, device=dev)
+        self.tab_f, self.tab_i, self.k1, self.d_targets = self._table_views(self.tab, n)
         # pinned staging, a ring of kStage sets: the host runs several steps ahead of the device, and an
         # asynchronous copy reads its pinned source when the DEVICE gets to it -- a set is rewritten only
         # after the event behind its last copy has completed
-        self._stage = [dict(tab_f=torch.zeros(5, n, 4, dtype=f32).pin_memory(),
-                            tab_i=torch.zeros(2, n, dtype=torch.int32).pin_memory(),
-                            k1=torch.zeros(2, 3, dtype=f32).pin_memory(),
-                            targets=torch.zeros(3, n, dtype=torch.int64).pin_memory(),   # targets, bd_targets, total_targets
-                            done=None) for _ in range(self.kStage)]
+        self._stage = []
+        for _ in range(self.kStage):
+            raw = torch.zeros(self._table_bytes(n), dtype=torch.uint8).pin_memory()
+            tf, ti, k1, tg = self._table_views(raw, n)
+            self._stage.append(dict(raw=raw, tab_f=tf, tab_i=ti, k1=k1, targets=tg, done=None))
         self._stage_i = 0
-        self.d_targets = torch.zeros(3, n, dtype=torch.int64, device=dev)
         eC, eK, eG = self.eC, self.eK, self.eG
         # The eval-mode forwards of one network are independent per sample.  clean_model (off the critical
         # path, second stream): the metric-only forward and the differentiated one run as ONE 2n-image batch
@@ -177,6 +180,10 @@ class AlternatedStep:
         self.sK_eval = eK.slot("K.eval2", 2 * n, hw)
         self.sG = eG.slot("G", n, hw)
         self.sF = self.eF.slot("F", n, hw) if self.eF is not None else None
+        # the heads read their labels straight out of the step table (bound before the plans marshal pointers)
+        lab = self.d_targets
+        self.sC_train.bufs["targets"], self.sC_eval.bufs["targets"], self.sC_met.bufs["targets"] = lab[2], lab[1], lab[0]
+        self.sK_eval.bufs["targets"], self.sK_eval.bufs["targets2"] = lab[3:5].view(-1), lab[5:7].view(-1)
         w_cm = float(self.opt.clean_model_weight)
         self.pl = dict(
             C_train_f=eC.forward_plan(self.sC_train, True), C_train_b=eC.backward_train_plan(self.sC_train),
@@ -191,11 +198,19 @@ class AlternatedStep:
         self.pl["K_bd_b"] = eK.backward_eval_plan(self.sK_bd, w_cm)
         if self.sF is not None:
             self.pl["F_f"] = self.eF.forward_plan(self.sF)
-        # head targets: (slot, engine, rows of d_targets for [first half, second half], targets2 row)
-        self._targets_of = {"C.train": (self.sC_train, eC, (2,), None), "C.eval": (self.sC_eval, eC, (1,), None),
-                            "C.metric": (self.sC_met, eC, (0,), None),
-                            "K.eval": (self.sK_eval, eK, (0, 0), 1)}
         self._gen_small: Dict[int, tuple] = {}
+
+    @staticmethod
+    def _table_bytes(n: int) -> int:
+        return 5 * n * 16 + 2 * n * 4 + 24 + 7 * n * 8
+
+    @staticmethod
+    def _table_views(raw: torch.Tensor, n: int):
+        o1 = 5 * n * 16
+        o2 = o1 + 2 * n * 4
+        o3 = o2 + 24
+        return (raw[:o1].view(f32).view(5, n, 4), raw[o1:o2].view(torch.int32).view(2, n),
+                raw[o2:o3].view(f32).view(2, 3), raw[o3:].view(torch.int64).view(7, n))
 
     def _side_stream(self) -> torch.cuda.Stream:
         if self.serial:            # kernel-level measurements: everything in line on the caller's stream
@@ -237,6 +252,9 @@ class AlternatedStep:
         h_targets[0].copy_(targets_cpu)
         h_targets[1].copy_(bd_targets_cpu)
         h_targets[2].copy_(tot)
+        h_targets[3].copy_(targets_cpu)
+        h_targets[4].copy_(targets_cpu)
+        h_targets[6].copy_(bd_targets_cpu)
         h_tab_i[0].copy_(idx_small)
         h_tab_i[1].copy_(idx_total)
         aug_ptr = []
@@ -246,20 +264,10 @@ class AlternatedStep:
             aug_ptr.append(self.tab_f[i].data_ptr() if a is not None else None)
         h_k1[0].copy_(torch.from_numpy(trigger.gaussian_kernel1d(rnd.sigma_c, opt.kernel_size)))
         h_k1[1].copy_(torch.from_numpy(trigger.gaussian_kernel1d(rnd.sigma_g, opt.kernel_size)))
-        self.tab_f.copy_(h_tab_f, non_blocking=True)
-        self.tab_i.copy_(h_tab_i, non_blocking=True)
-        self.k1.copy_(h_k1, non_blocking=True)
-        self.d_targets.copy_(h_targets, non_blocking=True)
+        self.tab.copy_(hs["raw"], non_blocking=True)
         hs["done"] = torch.cuda.Event()
         hs["done"].record()
         self.inputs.copy_(inputs, non_blocking=True)
-        self.cat_src[:n].copy_(self.inputs)
-        for name, (slot, eng, rows, t2) in self._targets_of.items():
-            h = eng.head_bufs(slot)
-            for i, r in enumerate(rows):
-                h["targets"][i * n:(i + 1) * n].copy_(self.d_targets[r])
-            if t2 is not None:
-                h["targets2"][n:].copy_(self.d_targets[t2])
         eC, eG, eK, eF, pl = self.eC, self.eG, self.eK, self.eF, self.pl
         for e in (eC, eG, eK) + ((eF,) if eF is not None else ()):
             e.refresh()
@@ -318,6 +326,9 @@ class AlternatedStep:
                 self.acc_side += (self.sF.bufs["logits"].argmax(1) == 1).sum()
             ev_side = torch.cuda.Event()
             ev_side.record()
+            # logged-only terms (:234-243): functions of the images and the poisoned images alone
+            self.acc[0] += self.mse.sum() / float(n * 3 * hw * hw)
+            self.acc[1] += self._grad_l2(self.inputs, self.bd)
 
         self._backward_allreduce(pl["C_train_b"], eC, prof)
         eC.fp.sgd_step(float(lr_c if lr_c is not None else opt.lr_C), grad_scale=1.0 / self.world)
@@ -348,11 +359,9 @@ class AlternatedStep:
         self._backward_allreduce(pl["G_b"], eG, prof)
         eG.fp.sgd_step(float(lr_g if lr_g is not None else opt.lr_G), grad_scale=1.0 / self.world)
         eG.mark_weights_dirty()
-        # ---- logged-only terms (:234-243)
-        torch.cuda.current_stream().wait_event(ev_met)   # the next step's Phase C rewrites netC's operands
-        self.acc[0] += self.mse.sum() / float(n * 3 * hw * hw)
-        self.acc[1] += self._grad_l2(self.inputs, self.bd)
-        self.acc[7] += n
+        # the next step rewrites the images, the step table and netC's operands under the second stream's readers
+        torch.cuda.current_stream().wait_event(ev_met)
+        self.samples += n
         self.steps_done += 1
 
     @staticmethod
@@ -399,7 +408,7 @@ class AlternatedStep:
         """One host sync: the running sums the reference prints each step (:257-290), over every
         batch size run since the last reset."""
         acc = self.acc.cpu()
-        total = max(float(acc[7]), 1.0)
+        total = max(float(self.samples), 1.0)
         w_cm = float(self.opt.clean_model_weight) or 1.0
         out = {"samples": total, "loss_c_sum": 0.0, "loss_ce_sum": 0.0, "clean_model_loss_sum": 0.0,
                "loss_l2_sum": float(acc[0]), "loss_grad_l2_sum": float(acc[1]), "clean_correct": 0, "bd_correct": 0,
@@ -421,6 +430,7 @@ class AlternatedStep:
         return out
 
     def reset_metrics(self) -> None:
+        self.samples = 0
         self.acc.zero_()
         self.acc_side.zero_()
         for sCt, sCe, sKe, sCm in self._slot_sets():
