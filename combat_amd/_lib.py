@@ -88,6 +88,10 @@ SIGNATURES = {
     "combat_norm_bwd_finalize": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_vp, c_vp, c_i64, c_vp]),
     "combat_norm_bwd_apply": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "combat_norm_act_fused": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "combat_norm_bwd_fused": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                        c_vp, c_i64, c_vp, c_vp]),
     "combat_group_stats_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "combat_unet_up_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_unet_up_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

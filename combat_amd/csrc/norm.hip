@@ -214,6 +214,247 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const __bf16 *__res
     }
 }
 
+// ------------------------------------------------------------------ fused statistics -> coefficients -> apply
+// One launch instead of finalize + element-wise pass (and, for small InstanceNorm groups, the separate
+// statistics pass): a workgroup owns (64 channels, one pixel chunk of one group); it first reduces the
+// group's partial rows for its channels -- every chunk of a group repeats that, <= 256 rows of 512 B --
+// or, with no partial rows, the group's pixels themselves (the group is then a single chunk), turns the
+// sums into coefficients with the formulas of the stand-alone finalize kernels, and applies them to its
+// pixels.  Chunk 0 publishes the per-channel results.  Thread = (8-channel octet co, pixel lane pl of 32).
+__device__ __forceinline__ void fused_combine(double (&s1)[8], double (&s2)[8], int tid) {
+    __shared__ double sh[4][8][16];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int m = 8; m < 64; m <<= 1) {
+            s1[e] += __shfl_xor(s1[e], m, 64);
+            s2[e] += __shfl_xor(s2[e], m, 64);
+        }
+    }
+    const int lane = tid & 63, w = tid >> 6, co = tid & 7;
+    if (lane < 8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            sh[w][co][e] = s1[e];
+            sh[w][co][8 + e] = s2[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s1[e] = sh[0][co][e] + sh[1][co][e] + sh[2][co][e] + sh[3][co][e];
+        s2[e] = sh[0][co][8 + e] + sh[1][co][8 + e] + sh[2][co][8 + e] + sh[3][co][8 + e];
+    }
+}
+
+struct FusedFwdArgs {
+    const __bf16 *x;
+    __bf16 *act;
+    const float *part;
+    int rpg, C;
+    long pxg;        // pixels per group
+    int chunk_px;
+    float count, eps, slope;
+    const float *gamma, *beta;
+    float *mean, *rstd, *scale, *shift, *running_mean, *running_var;
+    float momentum;
+    int64_t *nbt;
+};
+
+__global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs a) {
+    const int tid = threadIdx.x, co = tid & 7, pl = tid >> 3;
+    const int c = blockIdx.x * 64 + co * 8, chunk = blockIdx.y, g = blockIdx.z;
+    const bool live = c < a.C;
+    double s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.0;
+    if (live) {
+        if (a.part) {
+            for (int r = pl; r < a.rpg; r += 32) {
+                const float *p = a.part + (((long)g * a.rpg + r) * 2) * a.C + c;
+                float u[8], v[8];
+                load8f(p, u);
+                load8f(p + a.C, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += (double)u[e];
+                    s2[e] += (double)v[e];
+                }
+            }
+        } else {
+            float f1[8], f2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f1[e] = f2[e] = 0.f;
+            for (long i = pl; i < a.pxg; i += 32) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4 *>(a.x + ((long)g * a.pxg + i) * a.C + c), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f1[e] += v[e];
+                    f2[e] = fmaf(v[e], v[e], f2[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1[e] = (double)f1[e];
+                s2[e] = (double)f2[e];
+            }
+        }
+    }
+    fused_combine(s1, s2, tid);
+    float sc[8], sh[8];
+    const bool publish = live && chunk == 0 && pl == 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const double mean = s1[e] / a.count;
+        double var = s2[e] / a.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)a.eps);
+        const double gm = (a.gamma && live) ? (double)a.gamma[c + e] : 1.0;
+        const double bt = (a.beta && live) ? (double)a.beta[c + e] : 0.0;
+        sc[e] = (float)(gm * rstd);
+        sh[e] = (float)(bt - mean * gm * rstd);
+        if (publish) {
+            const long o = (long)g * a.C + c + e;
+            if (a.mean) a.mean[o] = (float)mean;
+            if (a.rstd) a.rstd[o] = (float)rstd;
+            if (a.scale) a.scale[o] = sc[e];
+            if (a.shift) a.shift[o] = sh[e];
+            if (a.running_mean) {
+                const double unb = a.count > 1.f ? var * a.count / (a.count - 1.0) : var;
+                a.running_mean[c + e] = (float)((1.0 - a.momentum) * a.running_mean[c + e] + a.momentum * mean);
+                a.running_var[c + e] = (float)((1.0 - a.momentum) * a.running_var[c + e] + a.momentum * unb);
+            }
+        }
+    }
+    if (a.nbt && blockIdx.x == 0 && chunk == 0 && g == 0 && tid == 0) *a.nbt += 1;
+    if (!live) return;
+    const long i0 = (long)chunk * a.chunk_px;
+    long i1 = i0 + a.chunk_px;
+    if (i1 > a.pxg) i1 = a.pxg;
+    for (long i = i0 + pl; i < i1; i += 32) {
+        const long off = ((long)g * a.pxg + i) * a.C + c;
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4 *>(a.x + off), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = fmaf(v[e], sc[e], sh[e]);
+            v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+        }
+        *reinterpret_cast<uint4 *>(a.act + off) = pack8(v);
+    }
+}
+
+struct FusedBwdArgs {
+    const __bf16 *dz, *x, *add;
+    __bf16 *dx;
+    const float *part;
+    int rpg, C;
+    long pxg;
+    int chunk_px;
+    float count;
+    const float *gamma, *mean, *rstd;
+    float *dgamma, *dbeta;
+};
+
+__global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const FusedBwdArgs a) {
+    const int tid = threadIdx.x, co = tid & 7, pl = tid >> 3;
+    const int c = blockIdx.x * 64 + co * 8, chunk = blockIdx.y, g = blockIdx.z;
+    const bool live = c < a.C;
+    double s1[8], s2[8];
+    float mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s1[e] = s2[e] = 0.0;
+        mu[e] = 0.f;
+        rs[e] = 1.f;
+    }
+    if (live) {
+        load8f(a.mean + (long)g * a.C + c, mu);
+        load8f(a.rstd + (long)g * a.C + c, rs);
+        if (a.part) {
+            for (int r = pl; r < a.rpg; r += 32) {
+                const float *p = a.part + (((long)g * a.rpg + r) * 2) * a.C + c;
+                float u[8], v[8];
+                load8f(p, u);
+                load8f(p + a.C, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += (double)u[e];
+                    s2[e] += (double)v[e];
+                }
+            }
+        } else {
+            float f1[8], f2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f1[e] = f2[e] = 0.f;
+            for (long i = pl; i < a.pxg; i += 32) {
+                const long off = ((long)g * a.pxg + i) * a.C + c;
+                float dv[8], xv[8];
+                unpack8(*reinterpret_cast<const uint4 *>(a.dz + off), dv);
+                unpack8(*reinterpret_cast<const uint4 *>(a.x + off), xv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f1[e] += dv[e];
+                    f2[e] = fmaf(dv[e], (xv[e] - mu[e]) * rs[e], f2[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1[e] = (double)f1[e];
+                s2[e] = (double)f2[e];
+            }
+        }
+    }
+    fused_combine(s1, s2, tid);
+    float ka[8], kb[8], kc[8];
+    const bool publish = live && chunk == 0 && pl == 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const double gm = (a.gamma && live) ? (double)a.gamma[c + e] : 1.0;
+        const double mean = mu[e], rstd = rs[e];
+        const double m1 = s1[e] / a.count, m2 = s2[e] / a.count;
+        ka[e] = (float)(gm * rstd);
+        kb[e] = (float)(-gm * rstd * rstd * m2);
+        kc[e] = (float)(gm * rstd * (mean * rstd * m2 - m1));
+        if (publish) {
+            if (a.dgamma) a.dgamma[c + e] = (float)s2[e];
+            if (a.dbeta) a.dbeta[c + e] = (float)s1[e];
+        }
+    }
+    if (!live) return;
+    const long i0 = (long)chunk * a.chunk_px;
+    long i1 = i0 + a.chunk_px;
+    if (i1 > a.pxg) i1 = a.pxg;
+    for (long i = i0 + pl; i < i1; i += 32) {
+        const long off = ((long)g * a.pxg + i) * a.C + c;
+        float dv[8], xv[8], o[8];
+        unpack8(*reinterpret_cast<const uint4 *>(a.dz + off), dv);
+        unpack8(*reinterpret_cast<const uint4 *>(a.x + off), xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(ka[e], dv[e], fmaf(kb[e], xv[e], kc[e]));
+        if (a.add) {
+            float ad[8];
+            unpack8(*reinterpret_cast<const uint4 *>(a.add + off), ad);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += ad[e];
+        }
+        *reinterpret_cast<uint4 *>(a.dx + off) = pack8(o);
+    }
+}
+
+constexpr int kFusedMaxRows = 256;     // partial rows a fused workgroup reduces itself (more: stage 1 first)
+constexpr long kFusedMaxDirect = 1024;  // pixels per group the fused kernels reduce without partial rows
+
+// pixel chunk per workgroup: >= 256 pixels (8 per lane, so the repeated row reduction stays small beside
+// it) and no more than ~1024 workgroups
+int fused_chunk(long pxg, int groups, int C) {
+    const long wg_c = (C + 63) / 64;
+    long chunk = 256;
+    while ((pxg + chunk - 1) / chunk * groups * wg_c > 1024) chunk *= 2;
+    return (int)chunk;
+}
+
 // returns the array the finalize kernel should read (possibly the stage-1 output)
 const float *maybe_stage1(const float *partials, int groups, int &rows_per_group, int C, float *scratch,
                           int64_t scratch_bytes, hipStream_t st, int &err) {
@@ -274,6 +515,60 @@ extern "C" int combat_norm_bwd_finalize(const float *partials, int32_t groups, i
     if (err) return err;
     BwdFinalizeArgs a{src, rpg, C, count, gamma, mean, rstd, ca, cb, cc, dgamma, dbeta};
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, st, a);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_norm_act_fused(const void *x, const float *partials, int32_t groups, int32_t rows_per_group,
+                                     int64_t px_per_group, int32_t C, float eps, float slope, const float *gamma,
+                                     const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                                     float *running_mean, float *running_var, float momentum,
+                                     int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes, void *act,
+                                     void *stream) {
+    if (!x || !act || groups <= 0 || px_per_group <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
+    if (partials ? rows_per_group <= 0 : px_per_group > kFusedMaxDirect) return COMBAT_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return COMBAT_EINVAL;
+    if (running_mean && groups != 1) return COMBAT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    int rpg = partials ? rows_per_group : 0;
+    const float *src = partials;
+    if (partials && rpg > kFusedMaxRows) {
+        int err;
+        src = maybe_stage1(partials, groups, rpg, C, scratch, scratch_bytes, st, err);
+        if (err) return err;
+    }
+    const int chunk = partials ? fused_chunk(px_per_group, groups, C) : (int)px_per_group;
+    FusedFwdArgs a{reinterpret_cast<const __bf16 *>(x), reinterpret_cast<__bf16 *>(act), src, rpg, C,
+                   (long)px_per_group, chunk, (float)px_per_group, eps, slope, gamma, beta, mean, rstd, scale, shift,
+                   running_mean, running_var, momentum, num_batches_tracked};
+    hipLaunchKernelGGL(norm_act_fused_kernel,
+                       dim3((C + 63) / 64, (unsigned)((px_per_group + chunk - 1) / chunk), groups), dim3(256), 0, st, a);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_norm_bwd_fused(const void *dz, const void *x, const void *add, const float *partials,
+                                     int32_t groups, int32_t rows_per_group, int64_t px_per_group, int32_t C,
+                                     const float *gamma, const float *mean, const float *rstd, float *dgamma,
+                                     float *dbeta, float *scratch, int64_t scratch_bytes, void *dx, void *stream) {
+    if (!dz || !x || !dx || !mean || !rstd || groups <= 0 || px_per_group <= 0 || C <= 0 || (C & 7))
+        return COMBAT_EINVAL;
+    if (partials ? rows_per_group <= 0 : px_per_group > kFusedMaxDirect) return COMBAT_EINVAL;
+    if ((dgamma || dbeta) && groups != 1) return COMBAT_EINVAL;
+    hipStream_t st = as_stream(stream);
+    int rpg = partials ? rows_per_group : 0;
+    const float *src = partials;
+    if (partials && rpg > kFusedMaxRows) {
+        int err;
+        src = maybe_stage1(partials, groups, rpg, C, scratch, scratch_bytes, st, err);
+        if (err) return err;
+    }
+    const int chunk = partials ? fused_chunk(px_per_group, groups, C) : (int)px_per_group;
+    FusedBwdArgs a{reinterpret_cast<const __bf16 *>(dz), reinterpret_cast<const __bf16 *>(x),
+                   reinterpret_cast<const __bf16 *>(add), reinterpret_cast<__bf16 *>(dx), src, rpg, C,
+                   (long)px_per_group, chunk, (float)px_per_group, gamma, mean, rstd, dgamma, dbeta};
+    hipLaunchKernelGGL(norm_bwd_fused_kernel,
+                       dim3((C + 63) / 64, (unsigned)((px_per_group + chunk - 1) / chunk), groups), dim3(256), 0, st, a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -160,6 +160,7 @@ class NormState:
         self.groups, self.C = groups, c
         self.mean, self.rstd, self.scale, self.shift = mk("mean"), mk("rstd"), mk("scale"), mk("shift")
         self.ca = self.cb = self.cc = None
+        self.pending = self.bpending = None    # statistics waiting for their fused finalize+apply launch
         self._slot, self._key = slot, key
 
     def bwd_coeffs(self):
@@ -358,10 +359,16 @@ class NetEngine:
         pass
 
     # ---- normalisation plumbing -----------------------------------------------------------
+    FUSED_DIRECT_PX = 1024   # pixels per group the fused norm kernels reduce themselves (kFusedMaxDirect, norm.hip)
+
     def _conv_norm(self, plan: Plan, slot: Slot, key: str, src, dst, pc: PackedConv, *, groups: int,
-                   gamma=None, beta=None, running=None, **conv_kw) -> NormState:
+                   gamma=None, beta=None, running=None, act_dst=None, slope: float = 0.0, defer: bool = False,
+                   **conv_kw) -> NormState:
         """conv + statistics of its raw output + finalize.  groups == 1: batch statistics
-        (optionally updating running stats); groups == N: instance statistics."""
+        (optionally updating running stats); groups == N: instance statistics.
+        act_dst: also materialise lrelu(norm(dst), slope) -- finalize and activation are then ONE launch
+        (combat_norm_act_fused).  defer: leave the finalize to the consumer's `_norm_act` (the activation
+        buffer belongs to the consuming layer)."""
         n, p, q, c = dst.shape
         pq, m = p * q, n * p * q
         a = ops.conv_args(src, dst, pc, 0, workspace=plan.workspace(src.device), **conv_kw)
@@ -371,13 +378,15 @@ class NetEngine:
         if st is None:
             st = NormState(slot, key, groups, c)
             slot.norm[key] = st
+        part = None
         if fused:
             part = slot.buf(key + ".part", (rows, 2, c), f32)
             a.stats_kind, a.stats = 1, part.data_ptr()
             rpg = rows if groups == 1 else rpi
-        plan.hold(a, part if fused else None)
+        plan.hold(a, part)
         plan.add(key + ".conv", lib.combat_conv_gemm, ctypes.byref(a))
-        if not fused:
+        one_launch = act_dst is not None or defer
+        if not fused and not (one_launch and pq <= self.FUSED_DIRECT_PX):
             g = _pow2_part(pq)
             parts = m // g
             part = slot.buf(key + ".part", (parts, 2, c), f32)
@@ -387,17 +396,34 @@ class NetEngine:
         if running is not None:
             rm, rv, nbt = running
         plan.hold(gamma, beta, rm, rv, nbt)
+        if one_launch:
+            st.pending = dict(x=dst, part=part, rpg=rpg if part is not None else 0, pxg=m // groups, key=key,
+                              gamma=gamma, beta=beta, rm=rm, rv=rv, nbt=nbt)
+            if act_dst is not None:
+                self._norm_act(plan, st, act_dst, slope)
+            return st
         plan.add(key + ".finalize", lib.combat_norm_finalize, part.data_ptr(), groups, rpg, c, float(m // groups),
                  1e-5, _p(gamma), _p(beta), st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
                  st.shift.data_ptr(), _p(rm), _p(rv), 0.1, _p(nbt), self._scratch.data_ptr(),
                  self._scratch.numel() * 4)
         return st
 
+    def _norm_act(self, plan: Plan, st: NormState, act_dst, slope: float):
+        """The deferred finalize of `st` + its activation tensor, one launch."""
+        q = st.pending
+        st.pending = None
+        x = q["x"]
+        plan.hold(x, act_dst, q["part"])
+        plan.add(q["key"] + ".finact", lib.combat_norm_act_fused, x.data_ptr(), _p(q["part"]), st.groups, q["rpg"],
+                 q["pxg"], st.C, 1e-5, float(slope), _p(q["gamma"]), _p(q["beta"]), st.mean.data_ptr(),
+                 st.rstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), _p(q["rm"]), _p(q["rv"]), 0.1,
+                 _p(q["nbt"]), self._scratch.data_ptr(), self._scratch.numel() * 4, act_dst.data_ptr())
+
     def _dgrad_norm(self, plan: Plan, slot: Slot, key: str, dy, dz, pc: PackedConv, x_pre, st: NormState, *,
                     group_stride: int, slope: float, gamma=None, dgamma=None, dbeta=None, add_pre=None):
         """dgrad whose epilogue applies the activation mask of the conv input (recomputed from the
-        saved pre-norm tensor x_pre) and emits the two norm-backward reductions; then finalize to
-        (ca, cb, cc).  Returns nothing: the caller applies the coefficients."""
+        saved pre-norm tensor x_pre) and emits the two norm-backward reductions.  The caller's
+        `_bwd_apply` turns them into coefficients and applies those in one launch."""
         n, p, q, c = dz.shape
         pq, m = p * q, n * p * q
         groups = st.groups
@@ -405,16 +431,17 @@ class NetEngine:
         a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask, workspace=plan.workspace(dy.device))
         rows, rpi = ops.conv_stats_layout(a)
         fused = (groups == 1) or (rpi > 0)
+        part, rpg = None, 0
         if fused:
             part = slot.buf(key + ".bpart", (rows, 2, c), f32)
             a.stats_kind, a.stats = 2, part.data_ptr()
             a.xh_mean, a.xh_rstd = st.mean.data_ptr(), st.rstd.data_ptr()
             rpg = rows if groups == 1 else rpi
-        plan.hold(a)
+        plan.hold(a, part)
         plan.add(key + ".dgrad", lib.combat_conv_gemm, ctypes.byref(a))
-        if not fused:
+        if not fused and pq > self.FUSED_DIRECT_PX:
             part, rpg = self._stats_bwd(plan, slot, key, dz, x_pre, st)
-        self._bwd_finalize(plan, key, part, rpg, m // groups, st, gamma, dgamma, dbeta)
+        st.bpending = dict(part=part, rpg=rpg, gamma=gamma, dgamma=dgamma, dbeta=dbeta)
 
     def _stats_bwd(self, plan: Plan, slot: Slot, key: str, dz, x_pre, st: NormState):
         n, p, q, c = dz.shape
@@ -427,21 +454,22 @@ class NetEngine:
                  st.mean.data_ptr(), st.rstd.data_ptr(), part.data_ptr())
         return part, (pq // g if st.groups > 1 else parts)
 
-    def _bwd_finalize(self, plan: Plan, key: str, part, rpg: int, count: int, st: NormState, gamma, dgamma, dbeta):
-        ca, cb, cc = st.bwd_coeffs()
-        plan.hold(part, gamma, dgamma, dbeta)
-        plan.add(key + ".bfinalize", lib.combat_norm_bwd_finalize, part.data_ptr(), st.groups, rpg, st.C,
-                 float(count), _p(gamma), st.mean.data_ptr(), st.rstd.data_ptr(), ca.data_ptr(), cb.data_ptr(),
-                 cc.data_ptr(), _p(dgamma), _p(dbeta), self._scratch.data_ptr(), self._scratch.numel() * 4)
-
-    @staticmethod
-    def _bwd_apply(plan: Plan, key: str, dz, x_pre, dx, st: NormState, add=None):
+    def _bwd_apply(self, plan: Plan, slot: Slot, key: str, dz, x_pre, dx, st: NormState, add=None):
+        """Norm backward: (sum dz, sum dz*xhat) -> coefficients -> dx = ca*dz + cb*x + cc (+ add), one launch.
+        The sums come from the rows `_dgrad_norm` left behind, or (no such rows) from dz / x_pre directly."""
         n, p, q, c = dz.shape
-        grouped = int(st.groups > 1)
-        ca, cb, cc = st.bwd_coeffs()
-        plan.hold(dz, x_pre, dx, add)
-        plan.add(key + ".bapply", lib.combat_norm_bwd_apply, dz.data_ptr(), x_pre.data_ptr(), _p(add), dx.data_ptr(),
-                 n * p * q, c, p * q if grouped else 0, grouped, ca.data_ptr(), cb.data_ptr(), cc.data_ptr())
+        pq, m = p * q, n * p * q
+        pend = getattr(st, "bpending", None) or dict(part=None, rpg=0, gamma=None, dgamma=None, dbeta=None)
+        st.bpending = None
+        part, rpg = pend["part"], pend["rpg"]
+        pxg = m // st.groups
+        if part is None and (st.groups == 1 or pq > self.FUSED_DIRECT_PX):
+            part, rpg = self._stats_bwd(plan, slot, key, dz, x_pre, st)
+        plan.hold(dz, x_pre, dx, add, part, pend["gamma"], pend["dgamma"], pend["dbeta"])
+        plan.add(key + ".bfused", lib.combat_norm_bwd_fused, dz.data_ptr(), x_pre.data_ptr(), _p(add), _p(part),
+                 st.groups, rpg, pxg, c, _p(pend["gamma"]), st.mean.data_ptr(), st.rstd.data_ptr(),
+                 _p(pend["dgamma"]), _p(pend["dbeta"]), self._scratch.data_ptr(), self._scratch.numel() * 4,
+                 dx.data_ptr())
 
 
 # --------------------------------------------------------------------------------------------
@@ -576,14 +604,12 @@ class PreActEngine(NetEngine):
         n, hw = slot.N, slot.hw
         cur = slot.buf("stem", (n, hw, hw, 64))
         first = self.blocks[0].bn1
-        st = self._conv_norm(P, slot, first.prefix, x, cur, self.stem, groups=1, gamma=first.gamma,
-                             beta=first.beta, running=(first.rm, first.rv, first.nbt))
-        aff = Affine(st.scale, st.shift, 0, True, 0.0)
+        a0 = slot.buf("b0.a0", cur.shape)
+        self._conv_norm(P, slot, first.prefix, x, cur, self.stem, groups=1, gamma=first.gamma, beta=first.beta,
+                        running=(first.rm, first.rv, first.nbt), act_dst=a0)
         chw = hw
         for b, blk in enumerate(self.blocks):
             ohw = chw // blk.stride
-            a0 = slot.buf("b%d.a0" % b, cur.shape)
-            rec_act(P, "b%d.act0" % b, cur, a0, aff)
             if blk.sc is not None:
                 resid = slot.buf("b%d.sc" % b, (n, ohw, ohw, blk.planes))
                 rec_conv(P, "b%d.sc" % b, a0, resid, blk.sc, 0)
@@ -592,14 +618,13 @@ class PreActEngine(NetEngine):
             y1 = slot.buf("b%d.y1" % b, (n, ohw, ohw, blk.planes))
             out = slot.buf("b%d.out" % b, (n, ohw, ohw, blk.planes))
             nxt = self.blocks[b + 1].bn1 if b + 1 < len(self.blocks) else None
-            st2 = self._conv_norm(P, slot, blk.bn2.prefix, a0, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
-                                  beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt))
             a1 = slot.buf("b%d.a1t" % b, y1.shape)
-            rec_act(P, "b%d.act1" % b, y1, a1, Affine(st2.scale, st2.shift, 0, True, 0.0))
+            self._conv_norm(P, slot, blk.bn2.prefix, a0, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
+                            beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt), act_dst=a1)
             if nxt is not None:
-                st = self._conv_norm(P, slot, nxt.prefix, a1, out, blk.conv2, groups=1, gamma=nxt.gamma,
-                                     beta=nxt.beta, running=(nxt.rm, nxt.rv, nxt.nbt), add_post=resid)
-                aff = Affine(st.scale, st.shift, 0, True, 0.0)
+                a0 = slot.buf("b%d.a0" % (b + 1), out.shape)
+                self._conv_norm(P, slot, nxt.prefix, a1, out, blk.conv2, groups=1, gamma=nxt.gamma, beta=nxt.beta,
+                                running=(nxt.rm, nxt.rv, nxt.nbt), add_post=resid, act_dst=a0)
             else:
                 rec_conv(P, "b%d.c2" % b, a1, out, blk.conv2, 0, add_post=resid)
             cur, chw = out, ohw
@@ -672,7 +697,7 @@ class PreActEngine(NetEngine):
                              slope=0.0, gamma=blk.bn2.gamma, dgamma=fp.grad_phys(pre + "bn2.weight"),
                              dbeta=fp.grad_phys(pre + "bn2.bias"))
             dy1 = slot.buf("g.b%d.dy1" % b, y1.shape)
-            self._bwd_apply(P, "g." + blk.bn2.prefix, dz2, y1, dy1, st2)
+            self._bwd_apply(P, slot, "g." + blk.bn2.prefix, dz2, y1, dy1, st2)
             tsc = None
             if blk.sc is not None:
                 rec_wgrad(P, "b%d.sc.wgrad" % b, a0, d_out, blk.sc, fp.grad_phys(pre + "shortcut.0.weight"))
@@ -684,7 +709,8 @@ class PreActEngine(NetEngine):
                              slope=0.0, gamma=blk.bn1.gamma, dgamma=fp.grad_phys(pre + "bn1.weight"),
                              dbeta=fp.grad_phys(pre + "bn1.bias"), add_pre=tsc)
             dxin = slot.buf("g.b%d.dx" % b, xin.shape)
-            self._bwd_apply(P, "g." + blk.bn1.prefix, dz1, xin, dxin, st1, add=None if blk.sc is not None else d_out)
+            self._bwd_apply(P, slot, "g." + blk.bn1.prefix, dz1, xin, dxin, st1,
+                            add=None if blk.sc is not None else d_out)
             d_out = dxin
             if b in (6, 4, 2):   # layer4 / layer3 / layer2 complete: their gradient range can travel
                 P.mark(fp.offsets[pre + "bn1.weight"][0])
@@ -783,25 +809,30 @@ class UnetEngine(NetEngine):
         rec_conv(P, "conv0_0", x, t00, pc["conv0_0"], 0, bias=bs["conv0_0"])
         lr_only = Affine(None, None, 0, True, self.LR)
 
-        def cn(name, src, s, c, pro):
-            # no bias here: InstanceNorm removes any per-(image, channel) constant, so
+        def cn(name, src, s, c, pro, defer=False):
+            # pro: None (src is used as is), an Affine (activation only), or the NormState of src whose
+            # finalize was deferred to here.  No bias: InstanceNorm removes any per-(image, channel) constant, so
             # IN(conv(x) + b) == IN(conv(x)) exactly, and leaving b out keeps the stored bf16
             # tensor better centred (less rounding error amplified by 1/sigma)
             dst = T(name, s, c)
             if pro is not None:   # materialise the activated input once ('a.<conv>'): forward and wgrad then need no prologue
                 act = slot.buf("a." + name, src.shape)
-                rec_act(P, name + ".act", src, act, pro)
+                if isinstance(pro, NormState):
+                    self._norm_act(P, pro, act, self.LR)
+                else:
+                    rec_act(P, name + ".act", src, act, pro)
                 src = act
-            st = self._conv_norm(P, slot, name, src, dst, pc[name], groups=n)
+            st = self._conv_norm(P, slot, name, src, dst, pc[name], groups=n, defer=defer)
             return dst, st
 
-        t01, s01 = cn("conv0_1", t00, h1, nf, lr_only)
-        t10, s10 = cn("conv1_0", t01, h2, nf * 2, self._in_aff(s01))
-        t11, s11 = cn("conv1_1", t10, h2, nf * 2, self._in_aff(s10))
-        t20, s20 = cn("conv2_0", t11, h3, nf * 4, self._in_aff(s11))
-        t21, s21 = cn("conv2_1", t20, h3, nf * 4, self._in_aff(s20))
-        t30, s30 = cn("conv3_0", t21, h4, nf * 8, self._in_aff(s21))
-        t31, s31 = cn("conv3_1", t30, h4, nf * 8, self._in_aff(s30))
+        # defer=True: the layer's InstanceNorm is finalised by the launch that writes the next conv's input
+        t01, s01 = cn("conv0_1", t00, h1, nf, lr_only, True)
+        t10, s10 = cn("conv1_0", t01, h2, nf * 2, s01, True)
+        t11, s11 = cn("conv1_1", t10, h2, nf * 2, s10, True)
+        t20, s20 = cn("conv2_0", t11, h3, nf * 4, s11, True)
+        t21, s21 = cn("conv2_1", t20, h3, nf * 4, s20, True)
+        t30, s30 = cn("conv3_0", t21, h4, nf * 8, s21, True)
+        t31, s31 = cn("conv3_1", t30, h4, nf * 8, s30)
 
         def up(level, y, sy, skip, ss, s_in, c):
             o = slot.buf("up%d" % level, (n, 2 * s_in, 2 * s_in, c))
@@ -812,14 +843,14 @@ class UnetEngine(NetEngine):
             return o
 
         u3 = up(3, t31, s31, None, None, h4, nf * 8)
-        tu31, su31 = cn("upconv3_1", u3, h3, nf * 8, None)
-        tu30, su30 = cn("upconv3_0", tu31, h3, nf * 4, self._in_aff(su31))
+        tu31, su31 = cn("upconv3_1", u3, h3, nf * 8, None, True)
+        tu30, su30 = cn("upconv3_0", tu31, h3, nf * 4, su31)
         u2 = up(2, tu30, su30, t21, s21, h3, nf * 4)
-        tu21, su21 = cn("upconv2_1", u2, h2, nf * 4, None)
-        tu20, su20 = cn("upconv2_0", tu21, h2, nf * 2, self._in_aff(su21))
+        tu21, su21 = cn("upconv2_1", u2, h2, nf * 4, None, True)
+        tu20, su20 = cn("upconv2_0", tu21, h2, nf * 2, su21)
         u1 = up(1, tu20, su20, t11, s11, h2, nf * 2)
-        tu11, su11 = cn("upconv1_1", u1, h1, nf * 2, None)
-        tu10, su10 = cn("upconv1_0", tu11, h1, nf, self._in_aff(su11))
+        tu11, su11 = cn("upconv1_1", u1, h1, nf * 2, None, True)
+        tu10, su10 = cn("upconv1_0", tu11, h1, nf, su11)
         u0 = up(0, tu10, su10, t01, s01, h1, nf)
         tu01, su01 = cn("upconv0_1", u0, hw, nf, None)
         rec_conv(P, "upconv0_0", tu01, self.output(slot), pc["upconv0_0"], 0, pro=self._in_aff(su01),
@@ -857,7 +888,7 @@ class UnetEngine(NetEngine):
             self._dgrad_norm(P, slot, "g." + src_name, dy, dz, pcv, src, st, group_stride=st.C, slope=self.LR,
                              add_pre=add_pre)
             dx = G(src_name + ".dx", src)
-            self._bwd_apply(P, "g." + src_name, dz, src, dx, st)
+            self._bwd_apply(P, slot, "g." + src_name, dz, src, dx, st)
             return dx
 
         def through_up(name, dy, pcv, level, y_name):
@@ -871,10 +902,8 @@ class UnetEngine(NetEngine):
             du = G("u%d" % level, y)
             P.add("up%d.bwd" % level, lib.combat_unet_up_bwd, du_full.data_ptr(), u.data_ptr(), n, y.shape[1],
                   y.shape[2], y.shape[3], du.data_ptr())
-            part, rpg = self._stats_bwd(P, slot, "g." + y_name, du, y, st)
-            self._bwd_finalize(P, "g." + y_name, part, rpg, y.shape[1] * y.shape[2], st, None, None, None)
             dy_out = G(y_name + ".dx", y)
-            self._bwd_apply(P, "g." + y_name, du, y, dy_out, st)
+            self._bwd_apply(P, slot, "g." + y_name, du, y, dy_out, st)    # sums taken from du / y directly
             return du, dy_out
 
         d = through_norm("upconv0_0", gz, pc["upconv0_0"], "upconv0_1")

@@ -244,6 +244,27 @@ int combat_norm_bwd_apply(const void *dz, const void *x, const void *add, void *
                           int32_t C, int32_t rows_per_group, int32_t grouped,
                           const float *ca, const float *cb, const float *cc, void *stream);
 
+/* Fused forms of the two chains above, one launch each (the step is bound by the number of dependent
+ * ~6 us launches, not by bytes):
+ *   combat_norm_act_fused  = combat_norm_finalize + combat_affine_act:  act = lrelu(x*scale + shift, slope)
+ *                            with (mean, rstd, scale, shift, running stats) published as by the finalize;
+ *   combat_norm_bwd_fused  = combat_norm_bwd_finalize + combat_norm_bwd_apply (ca/cb/cc stay in registers).
+ * x / dz / add / act / dx: bf16 [groups][px_per_group][C]; count = px_per_group.  partials as for the
+ * stand-alone calls ([groups*rows_per_group][2][C]; more than 256 rows per group are pre-reduced into
+ * `scratch`).  partials == NULL (px_per_group <= 1024): the sums are taken from the tensors themselves,
+ * which also replaces combat_group_stats / combat_group_stats_bwd for small InstanceNorm groups.
+ * Same formulas and fp64 finalisation as the stand-alone kernels (nn.BatchNorm2d / nn.InstanceNorm2d,
+ * classifier_models/preact_resnet.py:20-36, networks/models.py:278-313). */
+int combat_norm_act_fused(const void *x, const float *partials, int32_t groups, int32_t rows_per_group,
+                          int64_t px_per_group, int32_t C, float eps, float slope, const float *gamma,
+                          const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                          float *running_mean, float *running_var, float momentum, int64_t *num_batches_tracked,
+                          float *scratch, int64_t scratch_bytes, void *act, void *stream);
+int combat_norm_bwd_fused(const void *dz, const void *x, const void *add, const float *partials, int32_t groups,
+                          int32_t rows_per_group, int64_t px_per_group, int32_t C, const float *gamma,
+                          const float *mean, const float *rstd, float *dgamma, float *dbeta, float *scratch,
+                          int64_t scratch_bytes, void *dx, void *stream);
+
 /* per-part (sum dz, sum dz*xhat), same layout as combat_group_stats:
  * xhat = (x - xh_mean[i][c]) * xh_rstd[i][c], i = part / parts_per_image (0 => i = 0) */
 int combat_group_stats_bwd(const void *dz, const void *x, int32_t groups, int32_t rows_per_group,

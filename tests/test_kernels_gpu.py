@@ -609,6 +609,125 @@ def test_batchnorm_backward_coefficients(ops):
     assert rel_l2(dg, gp.grad) < 1e-4 and rel_l2(db, bp.grad) < 1e-4
 
 
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("rows,c,gran,groups", [(4096, 64, 32, 1), (2048, 128, 32, 1), (36864, 64, 32, 1),
+                                                (6 * 256, 64, 32, 6), (5 * 64, 136, 32, 5)])
+def test_norm_act_fused_equals_finalize_plus_activation(ops, rows, c, gran, groups):
+    """combat_norm_act_fused = combat_norm_finalize + combat_affine_act in one launch: same published
+    statistics (bit for bit: same rows, same fp64 finalisation) and the same activation tensor, for
+    BatchNorm (one group, incl. > 256 partial rows -> stage 1, running statistics) and InstanceNorm."""
+    from combat_amd._lib import lib
+    x = torch.randn(rows, c, generator=g(160)) * 1.7 + 0.8
+    xb = dev(x.to(bf16))
+    parts = rows // gran
+    partials = torch.empty(parts, 2, c, device="cuda")
+    ops.group_stats(xb, parts, gran, partials)
+    bn = groups == 1
+    gamma = dev(torch.rand(c, generator=g(161)) + 0.5) if bn else None
+    beta = dev(torch.randn(c, generator=g(162))) if bn else None
+    scratch = torch.empty(ops.norm_scratch_bytes(groups, c) // 4, device="cuda")
+    res = []
+    for fused in (False, True):
+        rm, rv = (dev(torch.zeros(c)), dev(torch.ones(c))) if bn else (None, None)
+        nbt = torch.zeros((), dtype=torch.int64, device="cuda") if bn else None
+        mean, rstd, scale, shift = (torch.empty(groups, c, device="cuda") for _ in range(4))
+        act = torch.empty_like(xb)
+        if fused:
+            ops.check(lib.combat_norm_act_fused(
+                xb.data_ptr(), partials.data_ptr(), groups, parts // groups, rows // groups, c, 1e-5, 0.2,
+                gamma.data_ptr() if bn else None, beta.data_ptr() if bn else None, mean.data_ptr(), rstd.data_ptr(),
+                scale.data_ptr(), shift.data_ptr(), rm.data_ptr() if bn else None, rv.data_ptr() if bn else None, 0.1,
+                nbt.data_ptr() if bn else None, scratch.data_ptr(), scratch.numel() * 4, act.data_ptr(), _stream()),
+                "combat_norm_act_fused")
+        else:
+            ops.norm_finalize(partials, groups, parts // groups, c, rows // groups, gamma=gamma, beta=beta, mean=mean,
+                              rstd=rstd, scale=scale, shift=shift, running_mean=rm, running_var=rv, nbt=nbt,
+                              scratch=scratch)
+            ops.check(lib.combat_affine_act(xb.data_ptr(), rows, c, scale.data_ptr(), shift.data_ptr(),
+                                            rows // groups if groups > 1 else 0, 0.2, act.data_ptr(), _stream()),
+                      "combat_affine_act")
+        res.append((mean, rstd, scale, shift, act, rm, rv, nbt))
+    for a, b in zip(*res):
+        if a is not None:
+            assert torch.equal(a, b)
+    xr = rb(x).view(groups, rows // groups, c)
+    mu, var = xr.mean(1, keepdim=True), xr.var(1, unbiased=False, keepdim=True)
+    ref = (xr - mu) / torch.sqrt(var + 1e-5)
+    if bn:
+        ref = ref * gamma.cpu() + beta.cpu()
+    assert rel_l2(res[1][4].float().view(groups, -1, c), F.leaky_relu(ref, 0.2)) < 4e-3
+
+
+@pytest.mark.parametrize("n,px,c", [(6, 4, 64), (5, 16, 256), (3, 256, 64), (2, 1024, 72)])
+def test_instance_norm_fused_from_the_tensors(ops, n, px, c):
+    """No partial rows: both fused kernels take their sums from the tensors (small InstanceNorm groups --
+    replaces group_stats(+_bwd) + finalize + apply).  Forward against F.instance_norm, backward against
+    autograd, with a residual term."""
+    from combat_amd._lib import lib
+    x = torch.randn(n, px, c, generator=g(163)) * 1.3 + 0.2
+    dy, add = torch.randn(n, px, c, generator=g(164)), torch.randn(n, px, c, generator=g(165))
+    xb, dyb, addb = dev(x.to(bf16)), dev(dy.to(bf16)), dev(add.to(bf16))
+    mean, rstd, scale, shift = (torch.empty(n, c, device="cuda") for _ in range(4))
+    act = torch.empty_like(xb)
+    ops.check(lib.combat_norm_act_fused(xb.data_ptr(), None, n, 0, px, c, 1e-5, 0.2, None, None, mean.data_ptr(),
+                                        rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.1, None, None,
+                                        0, act.data_ptr(), _stream()), "combat_norm_act_fused")
+    xr = rb(x).requires_grad_(True)
+    y = F.instance_norm(xr.permute(0, 2, 1), eps=1e-5).permute(0, 2, 1)
+    assert rel_l2(act.float(), F.leaky_relu(y, 0.2)) < 4e-3
+    assert rel_l2(mean, xr.detach().mean(1)) < 1e-5
+    assert rel_l2(xr.detach() * scale.cpu()[:, None] + shift.cpu()[:, None], y) < 1e-5
+    y.backward(rb(dy))
+    dx = torch.empty_like(xb)
+    ops.check(lib.combat_norm_bwd_fused(dyb.data_ptr(), xb.data_ptr(), addb.data_ptr(), None, n, 0, px, c, None,
+                                        mean.data_ptr(), rstd.data_ptr(), None, None, None, 0, dx.data_ptr(), _stream()),
+              "combat_norm_bwd_fused")
+    assert rel_l2(dx.float(), xr.grad + rb(add)) < 6e-3
+    # argument checks: more pixels per group than the direct form reduces
+    assert lib.combat_norm_act_fused(xb.data_ptr(), None, 1, 0, 2048, c, 1e-5, 0.2, None, None, mean.data_ptr(),
+                                     rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.1, None, None,
+                                     0, act.data_ptr(), _stream()) == -1
+
+
+@pytest.mark.parametrize("rows,c", [(2048, 128), (16384, 64)])
+def test_batchnorm_backward_fused(ops, rows, c):
+    """combat_norm_bwd_fused from partial rows = combat_norm_bwd_finalize + combat_norm_bwd_apply, bit for bit,
+    and against autograd (dx, dgamma, dbeta)."""
+    from combat_amd._lib import lib
+    gran = 32
+    x = torch.randn(rows, c, generator=g(166)) * 1.5 + 0.3
+    dz = torch.randn(rows, c, generator=g(167))
+    gamma = torch.rand(c, generator=g(168)) + 0.5
+    xb, dzb = dev(x.to(bf16)), dev(dz.to(bf16))
+    parts = rows // gran
+    partials = torch.empty(parts, 2, c, device="cuda")
+    ops.group_stats(xb, parts, gran, partials)
+    mean, rstd = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    scratch = torch.empty(ops.norm_scratch_bytes(1, c) // 4, device="cuda")
+    ops.norm_finalize(partials, 1, parts, c, rows, mean=mean, rstd=rstd, scratch=scratch)
+    ops.group_stats_bwd(dzb, xb, parts, gran, 0, mean, rstd, partials)
+    ca, cb, cc, dg, db, dg2, db2 = (torch.empty(c, device="cuda") for _ in range(7))
+    ops.norm_bwd_finalize(partials, 1, parts, c, rows, gamma=dev(gamma), mean=mean, rstd=rstd, ca=ca, cb=cb, cc=cc,
+                          dgamma=dg, dbeta=db, scratch=scratch)
+    dx, dx2 = torch.empty(rows, c, dtype=bf16, device="cuda"), torch.empty(rows, c, dtype=bf16, device="cuda")
+    ops.norm_bwd_apply(dzb, xb, dx, ca, cb, cc)
+    gm = dev(gamma)
+    ops.check(lib.combat_norm_bwd_fused(dzb.data_ptr(), xb.data_ptr(), None, partials.data_ptr(), 1, parts, rows, c,
+                                        gm.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dg2.data_ptr(), db2.data_ptr(),
+                                        scratch.data_ptr(), scratch.numel() * 4, dx2.data_ptr(), _stream()),
+              "combat_norm_bwd_fused")
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+    xr = rb(x).requires_grad_(True)
+    gp = gamma.clone().requires_grad_(True)
+    bp = torch.zeros(c, requires_grad=True)
+    F.batch_norm(xr, None, None, gp, bp, training=True).backward(rb(dz))
+    assert rel_l2(dx2.float(), xr.grad) < 6e-3
+    assert rel_l2(dg2, gp.grad) < 1e-4 and rel_l2(db2, bp.grad) < 1e-4
+
+
 def test_bn_eval_fold(ops):
     c = 96
     gm, bt = torch.rand(c, generator=g(68)) + 0.5, torch.randn(c, generator=g(69))
