@@ -200,12 +200,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # COMBAT_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (RCCL
+    # refuses two ranks on one device); the contract's runs use nccl = RCCL, one rank per GPU
+    backend = os.environ.get("COMBAT_DIST_BACKEND", "nccl")
+    local_rank = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend)
         pg = torch.distributed.group.WORLD
 
     from combat_amd import step as step_mod
@@ -251,7 +258,8 @@ def main():
     finite = all(np.isfinite(v) for v in metrics.values())
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # (every rank replays -- the step contains collectives -- rank 0 reports)
         # kernel-level numbers: replay with every launch in line on one stream (the timed region above
         # overlaps three streams, which stretches every kernel it brackets by what runs beside it)
         from combat_amd.engine import Plan
@@ -262,9 +270,10 @@ def main():
             st.run(x, t, prof=prof)
         torch.cuda.synchronize()
         st.serial = Plan.serial = False
-        roof = roofline_from(prof)
-        roof["replay"] = "serial (one stream), HIP events around each launch"
-        log("instrumented replay done: %s %.1f TFLOP/s" % (roof["kernel"], roof["achieved"]))
+        if rank == 0:
+            roof = roofline_from(prof)
+            roof["replay"] = "serial (one stream), HIP events around each launch"
+            log("instrumented replay done: %s %.1f TFLOP/s" % (roof["kernel"], roof["achieved"]))
     if world > 1:
         torch.distributed.barrier()
 

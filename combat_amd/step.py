@@ -299,8 +299,8 @@ class AlternatedStep:
         pl["C_train_f"].run(prof)
         # ---- fork (enqueued after the surrogate forward so that the main queue is never short of work while the
         # host feeds the second stream).  Everything Phase G does with the clean model and the detector depends only on the
-        # generator forward above -- not on Phase C -- so that chain (trigger, two augmentations, the
-        # detector, clean-model forward + input-gradient backward: ~1.5 ms of launches that individually
+        # generator forward above -- not on Phase C -- so that chain (trigger, two augmentations,
+        # clean-model forward + input-gradient backward: ~1.3 ms of launches that individually
         # leave most of the chip idle) runs on a second stream underneath Phase C.  It owns the clean
         # model's and the detector's engines and the buffers bd / mse / d_bd2; main waits for `ev_bd`
         # before it reads the poisoned images and for `ev_side` before the generator backward.
@@ -320,15 +320,8 @@ class AlternatedStep:
             pl["K_bd_b"].run(prof)
             ops.check(lib.combat_augment_bwd(self.sK_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[4], n, hw,
                                              self.d_bd2.data_ptr(), 0, s2), "augment 4 bwd")
-            if eF is not None:                 # :245-247 metric only
-                ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), s2), "dct")
-                pl["F_f"].run(prof)
-                self.acc_side += (self.sF.bufs["logits"].argmax(1) == 1).sum()
             ev_side = torch.cuda.Event()
             ev_side.record()
-            # logged-only terms (:234-243): functions of the images and the poisoned images alone
-            self.acc[0] += self.mse.sum() / float(n * 3 * hw * hw)
-            self.acc[1] += self._grad_l2(self.inputs, self.bd)
 
         self._backward_allreduce(pl["C_train_b"], eC, prof)
         eC.fp.sgd_step(float(lr_c if lr_c is not None else opt.lr_C), grad_scale=1.0 / self.world)
@@ -336,21 +329,32 @@ class AlternatedStep:
         eC.refresh()                       # re-pack bf16 operands, fold the new running stats
 
         # ================= Phase G (train_generator.py:216-255; generator forward and clean-model chain: above) =====
-        ev_c = torch.cuda.Event()              # netC updated and re-packed
-        ev_c.record()
-        with torch.cuda.stream(side):          # :227: accuracy of the updated netC on the clean images (logged only)
-            side.wait_event(ev_c)
-            ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, eC.input(self.sC_met).data_ptr(), None,
-                                             side.cuda_stream), "augment 2")
-            pl["C_met_f"].run(prof)
-            ev_met = torch.cuda.Event()
-            ev_met.record()
         torch.cuda.current_stream().wait_event(ev_bd)
         ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, xC.data_ptr(), None, st), "augment 3")
         pl["C_eval_f"].run(prof)               # :228, :231
         pl["C_bd_b"].run(prof)
         ops.check(lib.combat_augment_bwd(self.sC_bd.bufs["g.img"].data_ptr(), 8, aug_ptr[3], n, hw,
                                          self.d_bd.data_ptr(), 0, st), "augment 3 bwd")
+        # ---- everything that is only logged (:227 accuracy of the updated netC on the clean images, :245-247
+        # detector, :234-243 L2 / gradient-L2 terms) runs on the second stream from here on, underneath the
+        # generator backward -- a chain of input-gradient convolutions that leaves most of the chip idle --
+        # instead of beside the surrogate's forward/backward, which it would slow down
+        ev_late = torch.cuda.Event()
+        ev_late.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev_late)
+            s2 = side.cuda_stream
+            ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, eC.input(self.sC_met).data_ptr(), None, s2),
+                      "augment 2")
+            pl["C_met_f"].run(prof)
+            if eF is not None:
+                ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), s2), "dct")
+                pl["F_f"].run(prof)
+                self.acc_side += (self.sF.bufs["logits"].argmax(1) == 1).sum()
+            self.acc[0] += self.mse.sum() / float(n * 3 * hw * hw)
+            self.acc[1] += self._grad_l2(self.inputs, self.bd)
+            ev_met = torch.cuda.Event()
+            ev_met.record()
         torch.cuda.current_stream().wait_event(ev_side)     # ---- join
         self.d_bd += self.d_bd2
         l2_scale = float(opt.L2_weight) / float(n * 3 * hw * hw)          # :234, :253
