@@ -349,14 +349,17 @@ bool w3d_geometry(const combat_wgrad_args *a, W3dParams &p, int &smem) {
     return p.hpw >= 2 && p.hpw <= 4;
 }
 
-// number of pixel ranges: one workgroup per (tile, range), one workgroup per CU, >= 4 patches each.
-// With a workspace the partial sums cost plain stores; without, fp32 atomics (147 KB per workgroup)
-// against a ~24 MB budget.
+// number of pixel ranges: one workgroup per (tile, range), >= 4 patches each.  With a workspace the
+// partial sums cost plain stores (147 KB per workgroup, read back by the reduction launch) and the
+// launch is sized for HALF the CUs: weight gradients run on an auxiliary stream beside the
+// input-gradient chain, and 128 long-running 512-thread workgroups leave that chain room while
+// halving the slab traffic (measured on the whole step: 96-128 workgroups 5.07 ms, 192: 5.18,
+// 256: 5.30, 384: 5.81, 64: 5.14, 32: 5.69).  Without a workspace: fp32 atomics against a ~24 MB budget.
 int pick_split(const combat_wgrad_args *a, const W3dParams &p, bool with_ws) {
     const int base = p.tiles_k * p.tiles_c;
     int split = a->split;
     if (split <= 0) {
-        const int by_cus = (256 + base - 1) / base;
+        const int by_cus = ((with_ws ? 128 : 256) + base - 1) / base;
         const int by_atomics = 164 / base > 0 ? 164 / base : 1;
         split = with_ws || by_cus < by_atomics ? by_cus : by_atomics;
         const int by_work = (p.ntiles + 3) / 4;

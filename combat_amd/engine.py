@@ -917,6 +917,7 @@ class UnetEngine(NetEngine):
         P.mark(fp.offsets["upconv3_1.weight"][0])          # decoder gradients complete
         d = through_norm("conv3_1", d, pc["conv3_1"], "conv3_0")
         d = through_norm("conv3_0", d, pc["conv3_0"], "conv2_1", add_pre=du2)
+        P.mark(fp.offsets["conv3_0.weight"][0])            # + the two 512-channel encoder layers (14 MB of the rest)
         d = through_norm("conv2_1", d, pc["conv2_1"], "conv2_0")
         d = through_norm("conv2_0", d, pc["conv2_0"], "conv1_1", add_pre=du1)
         d = through_norm("conv1_1", d, pc["conv1_1"], "conv1_0")
