@@ -93,6 +93,10 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     const combat_conv_args &a = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef COMBAT_STAMPS
+    const unsigned long long c_entry = __builtin_readcyclecounter();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 
     int tile_m, tile_n;
     {
@@ -237,6 +241,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         p.stamps[blockIdx.x * 16 + 15] = ((unsigned long long)xcc << 32) | hw;
+        p.stamps[blockIdx.x * 16 + 14] = c_entry;
     }
 #endif
     issue_h(0, 0);
@@ -401,10 +406,11 @@ int conv3x3d_pick(const combat_conv_args *a) {
         return bn && applicable(a, bn) && geo_th(a, tile_bm(a->tile)) ? a->tile : 0;
     }
     if (!applicable(a, 64)) return applicable(a, 32) ? COMBAT_TILE_D128x32 : 0;
-    // skinny layers: 32-channel tiles double the workgroup count when 64-channel tiles cannot fill the
-    // chip.  (256-pixel tiles -- eight waves, half the weight DMA per MFMA -- exist for explicit requests
+    // skinny layers: 32-channel tiles double the workgroup count when 64-channel tiles give no more than
+    // one workgroup per CU (a workgroup alone on a CU issues in order: DMA pieces ~100 cycles each, then
+    // fragment reads, then MFMAs; a second one fills those gaps: 5-6 % on the 256-tile shapes).  (256-pixel tiles -- eight waves, half the weight DMA per MFMA -- exist for explicit requests
     // only: measured 0-15 % slower than three co-resident 128-pixel workgroups on every layer shape.)
-    return tiles_m_of(a) * (a->K / 64) < 192 ? COMBAT_TILE_D128x32 : COMBAT_TILE_D128x64;
+    return tiles_m_of(a) * (a->K / 64) <= 256 ? COMBAT_TILE_D128x32 : COMBAT_TILE_D128x64;
 }
 
 int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {

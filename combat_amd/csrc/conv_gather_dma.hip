@@ -16,6 +16,8 @@
 // free.  Stride-2 input gradients walk destination pixels parity-class-major (as conv_gemm.hip), so a
 // tile's pixels share their 1, 2 or 4 reachable taps and the others are skipped.
 // The epilogue is the shared DMA-kernel epilogue (conv_dma_epilogue.hpp).
+#include <cstdlib>
+
 #include "conv_dma_epilogue.hpp"
 
 namespace {
@@ -28,10 +30,20 @@ struct GatherParams {
     int tiles_m, tiles_n;
     int psplit, mq;              // parity-class-major pixel order (stride-2 dgrad), pixels per class
     int s_shift;
+    int pq_shift, q_shift;       // log2(P*Q), log2(Q) when both are powers of two (and, with psplit, Q >= 2, P*Q >= 4), else -1
     unsigned src_bytes, w_bytes, dst_bytes;
     int splits;                  // > 1: the reduction steps of a tile are divided among `splits` workgroups that
     float *ws;                   //      write fp32 slabs [split][tile][128][BN] here; conv_gather_finish_kernel combines
+    unsigned long long *stamps;  // profiling builds only (-DCOMBAT_STAMPS): per workgroup, cycles per phase
 };
+
+#ifdef COMBAT_STAMPS
+static unsigned long long *g_stamps_gather_host = nullptr;
+extern "C" int combat_debug_set_stamps_gather(void *p) { g_stamps_gather_host = (unsigned long long *)p; return 0; }
+#define GCLK() __builtin_readcyclecounter()
+#else
+#define GCLK() 0ull
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vm_lgkm0_bar() {
@@ -42,9 +54,12 @@ __device__ __forceinline__ void wait_vm_lgkm0_bar() {
 
 // FINISH = false: the convolution (whole, or one slab of a split reduction).  FINISH = true: the second
 // launch of a split reduction: sum the slabs into the accumulators and run the fused epilogue.
-template <int BN, bool FINISH>
+// NS = stages of the LDS ring (steps are issued NS - 1 ahead): 3 where two workgroups share a CU, 6 where a
+// launch has no more workgroups than CUs -- one workgroup alone has to cover the whole ~2500-cycle DMA
+// round trip with its own steps, and the LDS is free.
+template <int BN, bool FINISH, int NS>
 __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
-    constexpr int BM = 128, NS = 3;
+    constexpr int BM = 128;
     using T = TileCfg<BM, BN, 4>;           // four waves along the pixels: a wave owns 32 pixels x all BN channels
     using EC = EpiCfg<T>;
     constexpr int WPW = BN / 32;            // weight DMA pieces per wave and step
@@ -67,6 +82,9 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int C = a.C, H = a.H, W = a.W;
+#ifdef COMBAT_STAMPS
+    const unsigned long long c_start = GCLK(), w_start = wall_clock64();
+#endif
 
     // parity-class-major pixel order (psplit): class of this tile, its reachable taps (4 bits each)
     int pcls = 0, taplist = 0, ntap = p.ntaps;
@@ -77,13 +95,28 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         for (int r = (py + a.pad) & 1; r < a.R; r += 2)
             for (int sx = (px + a.pad) & 1; sx < a.S; sx += 2) taplist |= (r * a.S + sx) << (4 * ntap++);
     }
+    // destination pixel m -> (image, y, x).  Shifts when P*Q and Q are powers of two (every CIFAR / CelebA
+    // shape): eight emulated 32-bit divisions per lane were a third of the cycles in front of the main loop.
     auto decode = [&](int m, int &img, int &oy, int &ox) {
         if (p.psplit) {
             const int rem = m - pcls * p.mq, q4 = p.PQ >> 2, hq = a.Q >> 1;
-            img = rem / q4;
-            const int r2 = rem - img * q4, yy = r2 / hq;
+            int r2, yy;
+            if (p.pq_shift >= 0) {
+                img = rem >> (p.pq_shift - 2);
+                r2 = rem & (q4 - 1);
+                yy = r2 >> (p.q_shift - 1);
+            } else {
+                img = rem / q4;
+                r2 = rem - img * q4;
+                yy = r2 / hq;
+            }
             oy = 2 * yy + (pcls >> 1);
             ox = 2 * (r2 - yy * hq) + (pcls & 1);
+        } else if (p.pq_shift >= 0) {
+            img = m >> p.pq_shift;
+            const int rem = m & (p.PQ - 1);
+            oy = rem >> p.q_shift;
+            ox = rem & (a.Q - 1);
         } else {
             img = m / p.PQ;
             const int rem = m - img * p.PQ;
@@ -95,25 +128,51 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
 
-    // ---- this lane's four gathered rows (one per pixel DMA piece): image base, tap origin, channel chunk
-    int g_base[4], g_by[4], g_bx[4], g_ch[4];
+    // ---- this lane's four gathered rows (one per pixel DMA piece).  A step's source address is
+    //   pixoff[j] + (uniform offset of the step's tap and channel chunk)   if the tap reaches an input pixel,
+    // so everything per-lane is computed once: the row's byte offset for tap (0, 0) -- virtual: it may lie
+    // outside the tensor, only sums with a valid tap's offset are used -- and one validity bit per tap
+    // (padding, stride parity of the input gradient, rows beyond M).  A step then costs 3 VALU
+    // instructions per piece; evaluating the bounds per step made address arithmetic half of a step.
+    int pixoff[4], vmask[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int row = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
         const int m = m0 + row;
-        g_ch[j] = ((slot - (row & 6)) & 7) * 16;        // bytes inside the 64-channel chunk
+        const int ch = ((slot - (row & 6)) & 7) * 16;   // bytes inside the 64-channel chunk (slot rotation)
+        pixoff[j] = 0;
+        vmask[j] = 0;
         if (m < p.M) {
             int img, oy, ox;
             decode(m, img, oy, ox);
-            g_base[j] = img * H * W;
-            g_by[j] = a.mode == 0 ? oy * a.stride - a.pad : oy + a.pad;
-            g_bx[j] = a.mode == 0 ? ox * a.stride - a.pad : ox + a.pad;
-        } else {
-            g_base[j] = -1;
-            g_by[j] = g_bx[j] = 0;
+            const int by = a.mode == 0 ? oy * a.stride - a.pad : oy + a.pad;
+            const int bx = a.mode == 0 ? ox * a.stride - a.pad : ox + a.pad;
+            const int sh = a.mode == 0 ? 0 : p.s_shift;
+            pixoff[j] = ((img * H * W + (by >> sh) * W + (bx >> sh)) * C) * 2 + ch;
+            // tap (r, s) is valid iff row r and column s are: 3 + 3 tests, then the outer product of the bits
+            int rv = 0, cv = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                bool vr, vc;
+                if (a.mode == 0) {
+                    vr = (unsigned)(by + t) < (unsigned)H;
+                    vc = (unsigned)(bx + t) < (unsigned)W;
+                } else {
+                    const int ty = by - t, tx = bx - t;
+                    vr = ty >= 0 && ((ty & (a.stride - 1)) == 0) && (ty >> sh) < H;
+                    vc = tx >= 0 && ((tx & (a.stride - 1)) == 0) && (tx >> sh) < W;
+                }
+                rv |= (int)(vr && t < a.R) << t;
+                cv |= (int)(vc && t < a.S) << t;
+            }
+            if (a.S == 3) vmask[j] = ((rv & 1) ? cv : 0) | ((rv & 2) ? cv << 3 : 0) | ((rv & 4) ? cv << 6 : 0);
+            else vmask[j] = rv & cv & 1;     // 1x1
         }
-        asm volatile("" : "+v"(g_base[j]), "+v"(g_by[j]), "+v"(g_bx[j]), "+v"(g_ch[j]));
+        asm volatile("" : "+v"(pixoff[j]), "+v"(vmask[j]));
     }
+#ifdef COMBAT_STAMPS
+    const unsigned long long c_pix = GCLK();
+#endif
     unsigned wvoff[WPW];
 #pragma unroll
     for (int j = 0; j < WPW; ++j) {
@@ -126,22 +185,11 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         const int j_ = g / p.cpt, cc = g - j_ * p.cpt;
         const int tap = p.psplit ? (taplist >> (4 * j_)) & 15 : j_;
         const int r = (a.S == 3) ? ((tap * 11) >> 5) : tap, s = tap - r * a.S;
+        const int toff = a.mode == 0 ? ((r * W + s) * C + cc * 64) * 2
+                                     : (cc * 64 - ((r >> p.s_shift) * W + (s >> p.s_shift)) * C) * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int iy, ix;
-            bool v = g_base[j] >= 0;
-            if (a.mode == 0) {
-                iy = g_by[j] + r;
-                ix = g_bx[j] + s;
-                v = v && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-            } else {
-                const int ty = g_by[j] - r, tx = g_bx[j] - s;
-                v = v && ty >= 0 && tx >= 0 && (((ty | tx) & (a.stride - 1)) == 0);
-                iy = ty >> p.s_shift;
-                ix = tx >> p.s_shift;
-                v = v && iy < H && ix < W;
-            }
-            const unsigned off = v ? (unsigned)(((g_base[j] + iy * W + ix) * C + cc * 64) * 2 + g_ch[j]) : kDmaOob;
+            const unsigned off = ((vmask[j] >> tap) & 1) ? (unsigned)(pixoff[j] + toff) : kDmaOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(smem + sbase + (wid + 4 * j) * 1024), 16, off, 0, 0, 0);
         }
         const int soff = (tap * C + cc * 64) * 2;
@@ -163,6 +211,7 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     for (int i = 0; i < T::FN; ++i)
 #pragma unroll
         for (int j = 0; j < T::FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    unsigned long long t_mid = 0, ph[5] = {0, 0, 0, 0, 0};
     auto compute = [&](auto stage_tag) __attribute__((always_inline)) {
         const unsigned char *pb = smem + decltype(stage_tag)::value * SBYTES + wid * 32 * 128;
         const unsigned char *wb = smem + decltype(stage_tag)::value * SBYTES + PBYTES;
@@ -175,6 +224,11 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
             for (int i = 0; i < T::FN; ++i) fw[ks][i] = *reinterpret_cast<const bf16x8_t *>(wb + fa[ks] + i * 2048);
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef COMBAT_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t_mid = GCLK();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -185,6 +239,40 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // ---- ring of three stages, steps issued two ahead; unrolled over the stages so that every LDS
+    // address is "register + immediate".  A launch with zero reachable steps (1x1 stride-2 input gradient,
+    // odd pixel classes) still runs the epilogue on zero accumulators.
+    using std::integral_constant;
+    const int fr = lane & 15, fq = lane >> 4;
+    const size_t slab = (size_t)BM * BN;        // floats per (split, tile)
+    const int nsteps_all = ntap * p.cpt;
+    int g_lo = 0, nsteps = nsteps_all;
+    if (p.splits > 1) {
+        const int per = (nsteps_all + p.splits - 1) / p.splits;
+        g_lo = sp * per;
+        nsteps = nsteps_all - g_lo < per ? nsteps_all - g_lo : per;
+        if (nsteps < 0) nsteps = 0;
+    }
+    const bool whole = p.splits <= 1;           // this workgroup also runs the epilogue
+    constexpr int PF = 3;                       // epilogue fetch this many steps before the end
+    auto issue_at = [&](int g, int stage) __attribute__((always_inline)) {   // stage is uniform: one taken branch
+        if (stage == 0) issue(g, integral_constant<int, 0>{});
+        else if (stage == 1) issue(g, integral_constant<int, 1>{});
+        else if (stage == 2 || NS == 3) issue(g, integral_constant<int, 2>{});
+        else if (stage == 3 || NS == 4) issue(g, integral_constant<int, (NS > 3 ? 3 : 0)>{});
+        else if (stage == 4 || NS == 5) issue(g, integral_constant<int, (NS > 4 ? 4 : 0)>{});
+        else issue(g, integral_constant<int, (NS > 5 ? 5 : 0)>{});
+    };
+    if (!FINISH) {   // the first steps fly while the epilogue rows are decoded below
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q)
+            if (q < nsteps) issue_at(g_lo + q, q);
+    }
+#ifdef COMBAT_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c_iss = GCLK();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     // ---- fused epilogue operands: fetched PF steps before the end
     EpiRegs<T> epi;
     epi_init<T>(epi, lane, wid, n0, [&](int row) -> long {
@@ -196,12 +284,11 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         return (long)((img * a.P + oy) * a.Q + ox) * a.K;
     });
 
-    // ---- ring of three stages, steps issued two ahead; unrolled over the stages so that every LDS
-    // address is "register + immediate".  A launch with zero reachable steps (1x1 stride-2 input gradient,
-    // odd pixel classes) still runs the epilogue on zero accumulators.
-    using std::integral_constant;
-    const int fr = lane & 15, fq = lane >> 4;
-    const size_t slab = (size_t)BM * BN;        // floats per (split, tile)
+#ifdef COMBAT_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long c_epi = GCLK();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (FINISH) {
         // ---- second launch of a split reduction: accumulators = sum of the slabs (fragment layout), epilogue
         epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
@@ -219,43 +306,73 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
                       m0 + BM > p.M, p.PQ);
         return;
     }
-    const int nsteps_all = ntap * p.cpt;
-    int g_lo = 0, nsteps = nsteps_all;
-    if (p.splits > 1) {
-        const int per = (nsteps_all + p.splits - 1) / p.splits;
-        g_lo = sp * per;
-        nsteps = nsteps_all - g_lo < per ? nsteps_all - g_lo : per;
-        if (nsteps < 0) nsteps = 0;
-    }
-    const bool whole = p.splits <= 1;           // this workgroup also runs the epilogue
-    constexpr int PF = 3;                       // epilogue fetch this many steps before the end
-    if (nsteps > 0) issue(g_lo, integral_constant<int, 0>{});
-    if (nsteps > 1) issue(g_lo + 1, integral_constant<int, 1>{});
+    // wait until step `g + 1` has landed while the `k` younger steps issued after it stay in flight
+    auto wait_next = [&](int k) __attribute__((always_inline)) {
+        if (NS > 5 && k >= 4) wait_vm_lgkm0_bar<4 * NDMA>();
+        else if (NS > 4 && k == 3) wait_vm_lgkm0_bar<3 * NDMA>();
+        else if (NS > 3 && k == 2) wait_vm_lgkm0_bar<2 * NDMA>();
+        else if (k == 1) wait_vm_lgkm0_bar<NDMA>();
+        else wait_vm_lgkm0_bar<0>();
+    };
     if (whole && nsteps <= PF) epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
-    if (nsteps > 1 && (nsteps > PF || !whole)) wait_vm_lgkm0_bar<NDMA>(); else wait_vm_lgkm0_bar<0>();
     bool fetched = !whole || nsteps <= PF;      // (a slab never fetches: `fetched` then only selects the plain waits)
     const bool drain = whole;                   // after the epilogue fetch every wait drains the queue
+    {
+        const int young = (nsteps < NS - 1 ? nsteps : NS - 1) - 1;   // steps in flight behind step 0
+        wait_next(drain && fetched ? 0 : (young > 0 ? young : 0));
+    }
     auto body = [&](auto stage_tag, int g) __attribute__((always_inline)) {
-        constexpr int stage = decltype(stage_tag)::value, nstage = (stage + 2) % NS;
-        const bool ahead = g + 2 < nsteps;
-        if (ahead) issue(g_lo + g + 2, integral_constant<int, nstage>{});
+        constexpr int stage = decltype(stage_tag)::value, nstage = (stage + NS - 1) % NS;
+        const bool ahead = g + NS - 1 < nsteps;
+        const unsigned long long c0 = GCLK();
+        if (ahead) issue(g_lo + g + NS - 1, integral_constant<int, nstage>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long c1 = GCLK();
         const bool fetch_now = whole && !fetched && g + PF >= nsteps;
         if (fetch_now) {
             epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
             fetched = true;
         }
         compute(integral_constant<int, stage>{});
-        // step g + 1 must have landed; younger: step g + 2 (if issued) and, if issued after step g + 1's
+        // step g + 1 must have landed; younger: the steps issued after it and, if issued after step g + 1's
         // operands, the epilogue fetches.  Keep it simple and exact: drain everything whenever the
         // epilogue fetch is in flight (at most PF waits per launch).
-        if (ahead && !(drain && fetched)) wait_vm_lgkm0_bar<NDMA>(); else wait_vm_lgkm0_bar<0>();
+        int young = (g + NS - 1 < nsteps ? g + NS - 1 : nsteps - 1) - (g + 1);
+        const unsigned long long c3 = GCLK();
+        wait_next(drain && fetched ? 0 : (young > 0 ? young : 0));
+#ifdef COMBAT_STAMPS
+        const unsigned long long c4 = GCLK();
+        ph[0] += c1 - c0; ph[1] += t_mid - c1; ph[2] += c3 - t_mid; ph[3] += c4 - c3; ph[4] += 1;
+#else
+        (void)c0; (void)c1; (void)c3;
+#endif
     };
+#ifdef COMBAT_STAMPS
+    const unsigned long long c_loop_start = GCLK();
+#endif
     for (int g = 0; g < nsteps; g += NS) {
         body(integral_constant<int, 0>{}, g);
         if (g + 1 < nsteps) body(integral_constant<int, 1>{}, g + 1);
         if (g + 2 < nsteps) body(integral_constant<int, 2>{}, g + 2);
+        if (NS > 3 && g + 3 < nsteps) body(integral_constant<int, (NS > 3 ? 3 : 0)>{}, g + 3);
+        if (NS > 4 && g + 4 < nsteps) body(integral_constant<int, (NS > 4 ? 4 : 0)>{}, g + 4);
+        if (NS > 5 && g + 5 < nsteps) body(integral_constant<int, (NS > 5 ? 5 : 0)>{}, g + 5);
     }
     (void)EC::NPF;
+#ifdef COMBAT_STAMPS
+    const unsigned long long c_loop_end = GCLK();
+    if (threadIdx.x == 0 && p.stamps) {
+        for (int q = 0; q < 5; ++q) p.stamps[blockIdx.x * 16 + q] = ph[q];
+        p.stamps[blockIdx.x * 16 + 5] = c_loop_start - c_start;
+        p.stamps[blockIdx.x * 16 + 6] = c_loop_end - c_loop_start;
+        p.stamps[blockIdx.x * 16 + 7] = wall_clock64() - w_start;
+        p.stamps[blockIdx.x * 16 + 8] = w_start;
+        p.stamps[blockIdx.x * 16 + 11] = c_pix - c_start;
+        p.stamps[blockIdx.x * 16 + 12] = c_iss - c_pix;
+        p.stamps[blockIdx.x * 16 + 13] = c_epi - c_iss;
+        p.stamps[blockIdx.x * 16 + 14] = c_loop_start - c_epi;
+    }
+#endif
     if (!whole) {   // this workgroup's slab, straight from the fragments (16 bytes per lane, 64 per row and quad)
         float *dst = p.ws + ((size_t)sp * p.tiles_m * p.tiles_n + tile) * slab;
 #pragma unroll
@@ -267,19 +384,27 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     }
     epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
                   m0 + BM > p.M, p.PQ);
+#ifdef COMBAT_STAMPS
+    if (threadIdx.x == 0 && p.stamps) {
+        p.stamps[blockIdx.x * 16 + 9] = GCLK() - c_loop_end;
+        p.stamps[blockIdx.x * 16 + 10] = wall_clock64();
+    }
+#endif
 }
 
+template <int BN, int NS>
+__global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_kernel(const GatherParams p) {
+    conv_gather_dma_body<BN, false, NS>(p);
+}
 template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_gather_dma_kernel(const GatherParams p) { conv_gather_dma_body<BN, false>(p); }
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv_gather_finish_kernel(const GatherParams p) { conv_gather_dma_body<BN, true>(p); }
+__global__ __launch_bounds__(256, 2) void conv_gather_finish_kernel(const GatherParams p) { conv_gather_dma_body<BN, true, 3>(p); }
 
 // Workgroups per tile for a launch with `tiles` tiles and `nsteps` reduction steps: split the reduction
 // only when the tiles alone leave most of the chip idle (skinny layers: 2x2 / 4x4 feature maps).
 int pick_splits(long tiles, int nsteps) {
     if (tiles >= 96 || nsteps < 8) return 1;
-    int s = (int)(256 / tiles);
-    if (s > 8) s = 8;
+    int s = (int)(512 / tiles);   // two workgroups per CU: one alone waits ~2000 cycles per gathered stage
+    if (s > 16) s = 16;
     if (s > nsteps / 4) s = nsteps / 4;
     return s < 2 ? 1 : s;
 }
@@ -302,6 +427,11 @@ int launch(const combat_conv_args *a, hipStream_t st) {
     p.psplit = psplit_ok(*a) && (p.M / 4) % 128 == 0;
     p.mq = p.M / 4;
     p.s_shift = a->stride == 2 ? 1 : 0;
+    p.pq_shift = p.q_shift = -1;
+    if ((p.PQ & (p.PQ - 1)) == 0 && (a->Q & (a->Q - 1)) == 0 && a->Q >= 2 && p.PQ >= 4) {
+        p.pq_shift = __builtin_ctz(p.PQ);
+        p.q_shift = __builtin_ctz(a->Q);
+    }
     p.src_bytes = (unsigned)((long)a->N * a->H * a->W * a->C * 2);
     p.w_bytes = (unsigned)((long)a->rows_pad * a->kpad * 2);
     p.dst_bytes = (unsigned)((long)p.M * a->K * 2);
@@ -310,20 +440,34 @@ int launch(const combat_conv_args *a, hipStream_t st) {
     const long need = (long)p.splits * p.tiles_m * p.tiles_n * 128 * BN * 4;
     if (p.splits > 1 && (!a->workspace || a->workspace_bytes < need)) p.splits = 1;
     p.ws = p.splits > 1 ? reinterpret_cast<float *>(a->workspace) : nullptr;
-    constexpr int stage = 3 * (128 * 128 + BN * 128);
+#ifdef COMBAT_STAMPS
+    p.stamps = g_stamps_gather_host;
+#else
+    p.stamps = nullptr;
+#endif
+    constexpr int stage = 128 * 128 + BN * 128;
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
-    constexpr int smem = stage > ep ? stage : ep;
-    auto kern = conv_gather_dma_kernel<BN>;
+    constexpr int smem3 = 3 * stage > ep ? 3 * stage : ep, smem6 = 6 * stage > ep ? 6 * stage : ep;
+    static_assert(smem6 <= 160 * 1024, "six stages must fit the CU's LDS");
+    auto kern3 = conv_gather_dma_kernel<BN, 3>;
+    auto kern6 = conv_gather_dma_kernel<BN, 6>;
     auto fin = conv_gather_finish_kernel<BN>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern6), hipFuncAttributeMaxDynamicSharedMemorySize, smem6) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) != hipSuccess)
             return COMBAT_ELAUNCH;
         attr_set = true;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(tiles * (p.splits > 1 ? p.splits : 1)), dim3(256), smem, st, p);
+    const int blocks = tiles * (p.splits > 1 ? p.splits : 1);
+    const int nsteps_wg = (nsteps + (p.splits > 1 ? p.splits : 1) - 1) / (p.splits > 1 ? p.splits : 1);
+    static const int deep_max = getenv("COMBAT_DEEP_MAX") ? atoi(getenv("COMBAT_DEEP_MAX")) : 256;
+    if (blocks <= deep_max && nsteps_wg > 3)   // one workgroup per CU at most: deep ring
+        hipLaunchKernelGGL(kern6, dim3(blocks), dim3(256), smem6, st, p);
+    else
+        hipLaunchKernelGGL(kern3, dim3(blocks), dim3(256), smem3, st, p);
     CB_LAUNCH_CHECK();
     if (p.splits > 1) {
         hipLaunchKernelGGL(fin, dim3(tiles), dim3(256), ep, st, p);

@@ -56,7 +56,7 @@ class Plan:
         """Scratch of this plan's convolutions (split reductions of skinny layers).  Per plan: the calls of
         one plan run one after the other on one stream, two plans may run concurrently."""
         if self._ws is None:
-            self._ws = torch.empty(16 << 20, dtype=torch.uint8, device=device)
+            self._ws = torch.empty(32 << 20, dtype=torch.uint8, device=device)
         return self._ws
 
     def mark(self, grad_offset: int) -> None:
