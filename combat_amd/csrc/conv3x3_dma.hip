@@ -116,7 +116,31 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
 
-    // ---- per-lane DMA source offsets (bytes): chunk / tap terms are added through the scalar offset
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int n = (wid + NW * j) * 8 + (lane >> 3), slot = lane & 7;
+        const int chunk = (slot - (n & 6)) & 7;
+        wvoff[j] = (unsigned)(((n0 + n) * a.kpad + chunk * 8) * 2);
+    }
+    // weights of loop position t of chunk cc (dgrad walks the filter taps mirrored: tap 8 - t)
+    auto issue_w = [&](int t, int cc, int slot) __attribute__((always_inline)) {
+        const int tap = a.mode == 0 ? t : 8 - t;
+        const int soff = (tap * C + cc * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(wring + slot * WBYTES + (wid + NW * j) * 1024), 16,
+                                                     wvoff[j], soff, 0, 0);
+    };
+
+    // The first three weight tiles go out before anything else is computed: their round trip (and the
+    // halo patch's, issued as soon as its per-lane offsets exist) overlaps the rest of the set-up --
+    // ~3000 cycles of address arithmetic in a kernel of 15-25 k.
+    DSTAMP(0);
+    issue_w(0, 0, 0);
+    issue_w(1, 0, 1);
+    issue_w(2, 0, 2);
+    // ---- per-lane DMA source offsets of the halo patch (bytes): the chunk term is added through the scalar offset
     unsigned hvoff[HPW];
 #pragma unroll
     for (int j = 0; j < HPW; ++j) {
@@ -128,28 +152,13 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         const bool ok = row < G::HROWS && hx < TW + 2 && img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         hvoff[j] = ok ? (unsigned)((((img * H + iy) * W + ix) * C + chunk * 8) * 2) : kOob;
     }
-    unsigned wvoff[WPW];
-#pragma unroll
-    for (int j = 0; j < WPW; ++j) {
-        const int n = (wid + NW * j) * 8 + (lane >> 3), slot = lane & 7;
-        const int chunk = (slot - (n & 6)) & 7;
-        wvoff[j] = (unsigned)(((n0 + n) * a.kpad + chunk * 8) * 2);
-    }
     auto issue_h = [&](int cc, int hbuf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < HPW; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(halo + hbuf * HBYTES + (wid + NW * j) * 1024), 16,
                                                      hvoff[j], cc * 128, 0, 0);
     };
-    // weights of loop position t of chunk cc (dgrad walks the filter taps mirrored: tap 8 - t)
-    auto issue_w = [&](int t, int cc, int slot) __attribute__((always_inline)) {
-        const int tap = a.mode == 0 ? t : 8 - t;
-        const int soff = (tap * C + cc * 64) * 2;
-#pragma unroll
-        for (int j = 0; j < WPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(wring + slot * WBYTES + (wid + NW * j) * 1024), 16,
-                                                     wvoff[j], soff, 0, 0);
-    };
+    issue_h(0, 0);
 
     // ---- per-lane fragment read offsets: pixel fragment j at column offset dx, k-step ks
     int pa[2][T::FM][3];
@@ -234,7 +243,6 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     bf16x8_t fpA[T::FM], fwA[T::FN], fpB[T::FM], fwB[T::FN];
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    DSTAMP(0);
 #ifdef COMBAT_STAMPS
     if (threadIdx.x == 0 && p.stamps) {
         unsigned hw, xcc;
@@ -244,11 +252,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         p.stamps[blockIdx.x * 16 + 14] = c_entry;
     }
 #endif
-    issue_h(0, 0);
-    issue_w(0, 0, 0);
-    issue_w(1, 0, 1);
-    issue_w(2, 0, 2);
-    wait_vm_lgkm0<2 * WPW>();
+    wait_vm_lgkm0<0>();      // the halo patch was issued last
     block_barrier();
     DSTAMP(1);
     read_frags(fpA, fwA, I0{}, I0{}, I0{});

@@ -16,8 +16,6 @@
 // free.  Stride-2 input gradients walk destination pixels parity-class-major (as conv_gemm.hip), so a
 // tile's pixels share their 1, 2 or 4 reachable taps and the others are skipped.
 // The epilogue is the shared DMA-kernel epilogue (conv_dma_epilogue.hpp).
-#include <cstdlib>
-
 #include "conv_dma_epilogue.hpp"
 
 namespace {
@@ -54,9 +52,7 @@ __device__ __forceinline__ void wait_vm_lgkm0_bar() {
 
 // FINISH = false: the convolution (whole, or one slab of a split reduction).  FINISH = true: the second
 // launch of a split reduction: sum the slabs into the accumulators and run the fused epilogue.
-// NS = stages of the LDS ring (steps are issued NS - 1 ahead): 3 where two workgroups share a CU, 6 where a
-// launch has no more workgroups than CUs -- one workgroup alone has to cover the whole ~2500-cycle DMA
-// round trip with its own steps, and the LDS is free.
+// NS = stages of the LDS ring (steps are issued NS - 1 ahead); 3 is what launches use (see launch()).
 template <int BN, bool FINISH, int NS>
 __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     constexpr int BM = 128;
@@ -95,6 +91,62 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         for (int r = (py + a.pad) & 1; r < a.R; r += 2)
             for (int sx = (px + a.pad) & 1; sx < a.S; sx += 2) taplist |= (r * a.S + sx) << (4 * ntap++);
     }
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
+    using std::integral_constant;
+    const int nsteps_all = ntap * p.cpt;
+    int g_lo = 0, nsteps = nsteps_all;
+    if (p.splits > 1) {
+        const int per = (nsteps_all + p.splits - 1) / p.splits;
+        g_lo = sp * per;
+        nsteps = nsteps_all - g_lo < per ? nsteps_all - g_lo : per;
+        if (nsteps < 0) nsteps = 0;
+    }
+    // ---- steps are issued strictly in order: (tap index, channel chunk) of the next one as running counters
+    // (a division per step was a tenth of it)
+    int jn = g_lo / p.cpt, ccn = g_lo - jn * p.cpt;
+    auto advance = [&](int &j_, int &cc) __attribute__((always_inline)) {
+        if (++cc == p.cpt) {
+            cc = 0;
+            ++j_;
+        }
+    };
+    auto tap_of = [&](int j_) __attribute__((always_inline)) { return p.psplit ? (taplist >> (4 * j_)) & 15 : j_; };
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int j = 0; j < WPW; ++j) {
+        const int n = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
+        wvoff[j] = (unsigned)(((n0 + n) * a.kpad + ((slot - (n & 6)) & 7) * 8) * 2);
+    }
+    auto issue_w = [&](int j_, int cc, auto stage_tag) __attribute__((always_inline)) {
+        constexpr int sbase = decltype(stage_tag)::value * SBYTES;
+        const int soff = (tap_of(j_) * C + cc * 64) * 2;
+#pragma unroll
+        for (int j = 0; j < WPW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(smem + sbase + PBYTES + (wid + 4 * j) * 1024), 16,
+                                                     wvoff[j], soff, 0, 0);
+    };
+    // dispatch on a uniform stage number (one taken branch)
+    auto at_stage = [&](int stage, auto &&f) __attribute__((always_inline)) {
+        if (stage == 0) f(integral_constant<int, 0>{});
+        else if (stage == 1) f(integral_constant<int, 1>{});
+        else if (stage == 2 || NS == 3) f(integral_constant<int, 2>{});
+        else if (stage == 3 || NS == 4) f(integral_constant<int, (NS > 3 ? 3 : 0)>{});
+        else if (stage == 4 || NS == 5) f(integral_constant<int, (NS > 4 ? 4 : 0)>{});
+        else f(integral_constant<int, (NS > 5 ? 5 : 0)>{});
+    };
+    // The weights of the first NS - 1 steps go out before anything per-pixel is computed: their round trip
+    // overlaps the ~4000 cycles of row decoding below (the rows follow as soon as their offsets exist).
+    if (!FINISH) {
+        int jw = jn, cw = ccn;
+#pragma unroll
+        for (int q = 0; q < NS - 1; ++q)
+            if (q < nsteps) {
+                at_stage(q, [&](auto st) __attribute__((always_inline)) { issue_w(jw, cw, st); });
+                advance(jw, cw);
+            }
+    }
+
     // destination pixel m -> (image, y, x).  Shifts when P*Q and Q are powers of two (every CIFAR / CelebA
     // shape): eight emulated 32-bit divisions per lane were a third of the cycles in front of the main loop.
     auto decode = [&](int m, int &img, int &oy, int &ox) {
@@ -124,9 +176,6 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
             ox = rem - oy * a.Q;
         }
     };
-
-    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
 
     // ---- this lane's four gathered rows (one per pixel DMA piece).  A step's source address is
     //   pixoff[j] + (uniform offset of the step's tap and channel chunk)   if the tap reaches an input pixel,
@@ -173,17 +222,10 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
 #ifdef COMBAT_STAMPS
     const unsigned long long c_pix = GCLK();
 #endif
-    unsigned wvoff[WPW];
-#pragma unroll
-    for (int j = 0; j < WPW; ++j) {
-        const int n = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
-        wvoff[j] = (unsigned)(((n0 + n) * a.kpad + ((slot - (n & 6)) & 7) * 8) * 2);
-    }
-    // reduction step g -> (filter tap, channel chunk); its operands go to ring stage `stage`
-    auto issue = [&](int g, auto stage_tag) __attribute__((always_inline)) {
+    // gathered pixel rows of reduction step (tap index j_, channel chunk cc) into ring stage `stage`
+    auto issue_a = [&](int j_, int cc, auto stage_tag) __attribute__((always_inline)) {
         constexpr int sbase = decltype(stage_tag)::value * SBYTES;
-        const int j_ = g / p.cpt, cc = g - j_ * p.cpt;
-        const int tap = p.psplit ? (taplist >> (4 * j_)) & 15 : j_;
+        const int tap = tap_of(j_);
         const int r = (a.S == 3) ? ((tap * 11) >> 5) : tap, s = tap - r * a.S;
         const int toff = a.mode == 0 ? ((r * W + s) * C + cc * 64) * 2
                                      : (cc * 64 - ((r >> p.s_shift) * W + (s >> p.s_shift)) * C) * 2;
@@ -192,11 +234,12 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
             const unsigned off = ((vmask[j] >> tap) & 1) ? (unsigned)(pixoff[j] + toff) : kDmaOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(smem + sbase + (wid + 4 * j) * 1024), 16, off, 0, 0, 0);
         }
-        const int soff = (tap * C + cc * 64) * 2;
-#pragma unroll
-        for (int j = 0; j < WPW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(smem + sbase + PBYTES + (wid + 4 * j) * 1024), 16,
-                                                     wvoff[j], soff, 0, 0);
+    };
+    // a step = its pixel rows, then its weights; the counters walk on
+    auto issue = [&](auto stage_tag) __attribute__((always_inline)) {
+        issue_a(jn, ccn, stage_tag);
+        issue_w(jn, ccn, stage_tag);
+        advance(jn, ccn);
     };
 
     // ---- fragment read offsets: 16 consecutive rows from a multiple of 16 -> rotation key = lane & 6
@@ -242,31 +285,17 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     // ---- ring of three stages, steps issued two ahead; unrolled over the stages so that every LDS
     // address is "register + immediate".  A launch with zero reachable steps (1x1 stride-2 input gradient,
     // odd pixel classes) still runs the epilogue on zero accumulators.
-    using std::integral_constant;
     const int fr = lane & 15, fq = lane >> 4;
     const size_t slab = (size_t)BM * BN;        // floats per (split, tile)
-    const int nsteps_all = ntap * p.cpt;
-    int g_lo = 0, nsteps = nsteps_all;
-    if (p.splits > 1) {
-        const int per = (nsteps_all + p.splits - 1) / p.splits;
-        g_lo = sp * per;
-        nsteps = nsteps_all - g_lo < per ? nsteps_all - g_lo : per;
-        if (nsteps < 0) nsteps = 0;
-    }
     const bool whole = p.splits <= 1;           // this workgroup also runs the epilogue
     constexpr int PF = 3;                       // epilogue fetch this many steps before the end
-    auto issue_at = [&](int g, int stage) __attribute__((always_inline)) {   // stage is uniform: one taken branch
-        if (stage == 0) issue(g, integral_constant<int, 0>{});
-        else if (stage == 1) issue(g, integral_constant<int, 1>{});
-        else if (stage == 2 || NS == 3) issue(g, integral_constant<int, 2>{});
-        else if (stage == 3 || NS == 4) issue(g, integral_constant<int, (NS > 3 ? 3 : 0)>{});
-        else if (stage == 4 || NS == 5) issue(g, integral_constant<int, (NS > 4 ? 4 : 0)>{});
-        else issue(g, integral_constant<int, (NS > 5 ? 5 : 0)>{});
-    };
-    if (!FINISH) {   // the first steps fly while the epilogue rows are decoded below
+    if (!FINISH) {   // ... and the pixel rows of those steps; the epilogue rows are decoded while all of it flies
 #pragma unroll
         for (int q = 0; q < NS - 1; ++q)
-            if (q < nsteps) issue_at(g_lo + q, q);
+            if (q < nsteps) {
+                at_stage(q, [&](auto st) __attribute__((always_inline)) { issue_a(jn, ccn, st); });
+                advance(jn, ccn);
+            }
     }
 #ifdef COMBAT_STAMPS
     __builtin_amdgcn_sched_barrier(0);
@@ -317,15 +346,19 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     if (whole && nsteps <= PF) epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
     bool fetched = !whole || nsteps <= PF;      // (a slab never fetches: `fetched` then only selects the plain waits)
     const bool drain = whole;                   // after the epilogue fetch every wait drains the queue
-    {
-        const int young = (nsteps < NS - 1 ? nsteps : NS - 1) - 1;   // steps in flight behind step 0
-        wait_next(drain && fetched ? 0 : (young > 0 ? young : 0));
+    {   // step 0 = the first weights (issued long ago) + the first pixel rows; younger: 4 row pieces per later step
+        const int young = (nsteps < NS - 1 ? nsteps : NS - 1) - 1;
+        if (drain && fetched || young <= 0) wait_vm_lgkm0_bar<0>();
+        else if (young == 1) wait_vm_lgkm0_bar<4>();
+        else if (NS > 3 && young == 2) wait_vm_lgkm0_bar<8>();
+        else if (NS > 4 && young == 3) wait_vm_lgkm0_bar<12>();
+        else wait_vm_lgkm0_bar<(NS > 5 ? 16 : 0)>();
     }
     auto body = [&](auto stage_tag, int g) __attribute__((always_inline)) {
         constexpr int stage = decltype(stage_tag)::value, nstage = (stage + NS - 1) % NS;
         const bool ahead = g + NS - 1 < nsteps;
         const unsigned long long c0 = GCLK();
-        if (ahead) issue(g_lo + g + NS - 1, integral_constant<int, nstage>{});
+        if (ahead) issue(integral_constant<int, nstage>{});
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long c1 = GCLK();
         const bool fetch_now = whole && !fetched && g + PF >= nsteps;
@@ -447,27 +480,21 @@ int launch(const combat_conv_args *a, hipStream_t st) {
 #endif
     constexpr int stage = 128 * 128 + BN * 128;
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
-    constexpr int smem3 = 3 * stage > ep ? 3 * stage : ep, smem6 = 6 * stage > ep ? 6 * stage : ep;
-    static_assert(smem6 <= 160 * 1024, "six stages must fit the CU's LDS");
-    auto kern3 = conv_gather_dma_kernel<BN, 3>;
-    auto kern6 = conv_gather_dma_kernel<BN, 6>;
+    constexpr int smem = 3 * stage > ep ? 3 * stage : ep;
+    // (A six-stage ring for launches of at most one workgroup per CU -- ring depth is a template parameter --
+    // changed nothing on the kernel alone and cost the step 1.5 %: a workgroup holding 144 KB of LDS keeps the
+    // other streams' workgroups off its CU.  What bounds a lone workgroup is in-order issue, not DMA latency.)
+    auto kern = conv_gather_dma_kernel<BN, 3>;
     auto fin = conv_gather_finish_kernel<BN>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(kern6), hipFuncAttributeMaxDynamicSharedMemorySize, smem6) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, smem3) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return COMBAT_ELAUNCH;
         attr_set = true;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    const int blocks = tiles * (p.splits > 1 ? p.splits : 1);
-    const int nsteps_wg = (nsteps + (p.splits > 1 ? p.splits : 1) - 1) / (p.splits > 1 ? p.splits : 1);
-    static const int deep_max = getenv("COMBAT_DEEP_MAX") ? atoi(getenv("COMBAT_DEEP_MAX")) : 256;
-    if (blocks <= deep_max && nsteps_wg > 3)   // one workgroup per CU at most: deep ring
-        hipLaunchKernelGGL(kern6, dim3(blocks), dim3(256), smem6, st, p);
-    else
-        hipLaunchKernelGGL(kern3, dim3(blocks), dim3(256), smem3, st, p);
+    hipLaunchKernelGGL(kern, dim3(tiles * (p.splits > 1 ? p.splits : 1)), dim3(256), smem, st, p);
     CB_LAUNCH_CHECK();
     if (p.splits > 1) {
         hipLaunchKernelGGL(fin, dim3(tiles), dim3(256), ep, st, p);
