@@ -43,6 +43,7 @@ constexpr unsigned kOob = kDmaOob;
 struct DmaParams {
     combat_conv_args a;
     int tiles_x, tiles_y, tiles_m, tiles_n;
+    int m_fastest;               // order of an XCD's contiguous tile range (each XCD has its own L2)
     int PQ, nchunks;
     unsigned src_bytes, w_bytes;
     unsigned long long *stamps;   // profiling builds only
@@ -103,8 +104,13 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         const int nb = gridDim.x, bid = blockIdx.x;
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
         const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tile_n = swz % p.tiles_n;
-        tile_m = swz / p.tiles_n;
+        if (p.m_fastest) {   // weights outweigh the input: an XCD's tiles share few weight rows, all pixels
+            tile_m = swz % p.tiles_m;
+            tile_n = swz / p.tiles_m;
+        } else {
+            tile_n = swz % p.tiles_n;
+            tile_m = swz / p.tiles_n;
+        }
     }
     const int n0 = tile_n * BN;
     const int tx_ = tile_m % p.tiles_x, ty_ = (tile_m / p.tiles_x) % p.tiles_y, ig = tile_m / (p.tiles_x * p.tiles_y);
@@ -345,6 +351,10 @@ void fill(const combat_conv_args *a, int BN, DmaParams &p) {
     p.tiles_y = a->H / G::TH;
     p.tiles_m = p.tiles_x * p.tiles_y * ((a->N + G::TI - 1) / G::TI);
     p.tiles_n = a->K / BN;
+    {   // per-XCD L2 footprint: (input / 8 + all weights) with channel tiles fastest, (input + weights / 8) otherwise
+        const long in_b = (long)a->N * a->H * a->W * a->C * 2, w_b = (long)a->K * a->C * 18;
+        p.m_fastest = in_b < w_b;   // (512-channel 4x4 layers: 19.3 -> 16.7 us)
+    }
     p.PQ = a->H * a->W;
     p.nchunks = a->C / 64;
     p.src_bytes = (unsigned)((long)a->N * a->H * a->W * a->C * 2);
@@ -414,7 +424,10 @@ int conv3x3d_pick(const combat_conv_args *a) {
     // one workgroup per CU (a workgroup alone on a CU issues in order: DMA pieces ~100 cycles each, then
     // fragment reads, then MFMAs; a second one fills those gaps: 5-6 % on the 256-tile shapes).  (256-pixel tiles -- eight waves, half the weight DMA per MFMA -- exist for explicit requests
     // only: measured 0-15 % slower than three co-resident 128-pixel workgroups on every layer shape.)
-    return tiles_m_of(a) * (a->K / 64) <= 256 ? COMBAT_TILE_D128x32 : COMBAT_TILE_D128x64;
+    // (4-pixel-wide maps: two halo images of 8 x 6 x 8 pixels leave room for one workgroup per CU whatever BN is,
+    // so there 32-channel tiles only pay while the 64-channel ones leave CUs empty)
+    const long wgs64 = tiles_m_of(a) * (a->K / 64);
+    return wgs64 < 192 || (wgs64 <= 256 && geo_tw(a) > 4) ? COMBAT_TILE_D128x32 : COMBAT_TILE_D128x64;
 }
 
 int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {

@@ -26,6 +26,7 @@ struct GatherParams {
     combat_conv_args a;
     int M, PQ, ntaps, cpt;       // dst pixels, P*Q, R*S, 64-channel chunks per tap
     int tiles_m, tiles_n;
+    int m_fastest;               // order of an XCD's contiguous tile range (per-XCD L2: input / 8 + weights, or input + weights / 8)
     int psplit, mq;              // parity-class-major pixel order (stride-2 dgrad), pixels per class
     int s_shift;
     int pq_shift, q_shift;       // log2(P*Q), log2(Q) when both are powers of two (and, with psplit, Q >= 2, P*Q >= 4), else -1
@@ -73,8 +74,13 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         sp = blockIdx.x / ntile;                       // slab of a split reduction (0 otherwise)
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tile_n = tile % p.tiles_n;
-        tile_m = tile / p.tiles_n;
+        if (p.m_fastest) {   // weights outweigh the input: an XCD's contiguous tiles share few weight rows, all pixels
+            tile_m = tile % p.tiles_m;
+            tile_n = tile / p.tiles_m;
+        } else {
+            tile_n = tile % p.tiles_n;
+            tile_m = tile / p.tiles_n;
+        }
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int C = a.C, H = a.H, W = a.W;
@@ -457,6 +463,7 @@ int launch(const combat_conv_args *a, hipStream_t st) {
     p.cpt = a->C / 64;
     p.tiles_m = (p.M + 127) / 128;
     p.tiles_n = a->K / BN;
+    p.m_fastest = (long)a->N * a->H * a->W * a->C * 2 < (long)a->K * a->C * p.ntaps * 2;
     p.psplit = psplit_ok(*a) && (p.M / 4) % 128 == 0;
     p.mq = p.M / 4;
     p.s_shift = a->stride == 2 ? 1 : 0;
