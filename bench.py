@@ -88,9 +88,9 @@ def conv_flops(a):
 
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
-    per the gfx950 correction + WRITE_SIZE, separate --pmc runs; profiles/r01_f_pmc_hbm_traffic.csv):
+    per the gfx950 correction + WRITE_SIZE, separate --pmc runs; profiles/r01_i_pmc_hbm_traffic.csv):
     PMC counters cannot be collected from inside this process.  None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.csv")
+    path = os.path.join(ROOT, "profiles", "r01_i_pmc_hbm_traffic.csv")
     try:
         tot = cnt = 0.0
         for line in open(path):
@@ -115,18 +115,28 @@ def roofline_from(prof):
         g[0] += conv_flops(a)
         g[1] += e0.elapsed_time(e1) * 1e-3
         g[2] += 1
-    tile, (fl, sec, cnt) = max(groups.items(), key=lambda kv: kv[1][1])
+    # the dominant kernel = the __global__ template with the most device time, over all its tile
+    # instantiations (rocprofv3 lists each instantiation; "all_conv_tiles" below does too)
+    fams = {}
+    for t, (f, s_, c) in groups.items():
+        fam = TILE_NAMES.get(t, str(t)).split("<")[0]
+        g = fams.setdefault(fam, [0.0, 0.0, 0])
+        g[0] += f
+        g[1] += s_
+        g[2] += c
+    fam, (fl, sec, cnt) = max(fams.items(), key=lambda kv: kv[1][1])
     achieved = fl / sec / 1e12
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-        "traffic": pmc_traffic(TILE_NAMES.get(tile, str(tile)).split(">")[0] + ","),
-        "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r01_f_pmc_hbm_traffic.csv)",
-        "kernel": TILE_NAMES.get(tile, str(tile)), "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
+        "traffic": pmc_traffic(fam + "<"),
+        "traffic_unit": "HBM bytes per launch, launch-weighted over the instantiations (rocprofv3 PMC passes, "
+                        "profiles/r01_i_pmc_hbm_traffic.csv)",
+        "kernel": fam + " (all tile instantiations)", "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
         "gflop_per_launch": round(fl / cnt / 1e9, 3),
-        "all_conv_tiles": {TILE_NAMES.get(t, str(t)): {"launches": c, "avg_us": round(s / c * 1e6, 2),
-                                                      "tflops": round(f / s / 1e12, 1)}
-                           for t, (f, s, c) in sorted(groups.items())},
+        "all_conv_tiles": {TILE_NAMES.get(t, str(t)): {"launches": c, "avg_us": round(s_ / c * 1e6, 2),
+                                                      "tflops": round(f / s_ / 1e12, 1)}
+                           for t, (f, s_, c) in sorted(groups.items())},
     }
 
 
