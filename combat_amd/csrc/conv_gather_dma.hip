@@ -265,27 +265,29 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         const unsigned char *pb = smem + decltype(stage_tag)::value * SBYTES + wid * 32 * 128;
         const unsigned char *wb = smem + decltype(stage_tag)::value * SBYTES + PBYTES;
         bf16x8_t fp[2][T::FM], fw[2][T::FN];
+        // both k-steps' fragment reads are issued up front, in k-step order: the MFMAs of the first wait for
+        // its six or four reads only, the second k-step's reads land behind them
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int j = 0; j < T::FM; ++j) fp[ks][j] = *reinterpret_cast<const bf16x8_t *>(pb + fa[ks] + j * 2048);
 #pragma unroll
             for (int i = 0; i < T::FN; ++i) fw[ks][i] = *reinterpret_cast<const bf16x8_t *>(wb + fa[ks] + i * 2048);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #ifdef COMBAT_STAMPS
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         t_mid = GCLK();
         __builtin_amdgcn_sched_barrier(0);
 #endif
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < T::FN; ++i)
 #pragma unroll
                 for (int j = 0; j < T::FM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[ks][i], fp[ks][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
 
     // ---- ring of three stages, steps issued two ahead; unrolled over the stages so that every LDS

@@ -221,8 +221,10 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const __bf16 *__res
 // or, with no partial rows, the group's pixels themselves (the group is then a single chunk), turns the
 // sums into coefficients with the formulas of the stand-alone finalize kernels, and applies them to its
 // pixels.  Chunk 0 publishes the per-channel results.  Thread = (8-channel octet co, pixel lane pl of 32).
-__device__ __forceinline__ void fused_combine(double (&s1)[8], double (&s2)[8], int tid) {
-    __shared__ double sh[4][8][16];
+// Wave-level sums of the 32 pixel lanes, one LDS row per wave; then thread ch < 64 owns channel ch of the
+// workgroup's 64: it adds the four waves (fixed order) and does the fp64 finalisation ONCE per channel --
+// with every lane finalising its own eight channels the div / sqrt chains were half of the launch.
+__device__ __forceinline__ void fused_combine(double (&s1)[8], double (&s2)[8], int tid, double (*sh)[8][16]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -240,11 +242,12 @@ __device__ __forceinline__ void fused_combine(double (&s1)[8], double (&s2)[8], 
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        s1[e] = sh[0][co][e] + sh[1][co][e] + sh[2][co][e] + sh[3][co][e];
-        s2[e] = sh[0][co][8 + e] + sh[1][co][8 + e] + sh[2][co][8 + e] + sh[3][co][8 + e];
-    }
+}
+
+__device__ __forceinline__ void fused_channel_sums(double (*sh)[8][16], int ch, double &t1, double &t2) {
+    const int co = ch >> 3, e = ch & 7;
+    t1 = sh[0][co][e] + sh[1][co][e] + sh[2][co][e] + sh[3][co][e];
+    t2 = sh[0][co][8 + e] + sh[1][co][8 + e] + sh[2][co][8 + e] + sh[3][co][8 + e];
 }
 
 struct FusedFwdArgs {
@@ -301,33 +304,44 @@ __global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs 
             }
         }
     }
-    fused_combine(s1, s2, tid);
-    float sc[8], sh[8];
-    const bool publish = live && chunk == 0 && pl == 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const double mean = s1[e] / a.count;
-        double var = s2[e] / a.count - mean * mean;
+    __shared__ double sums[4][8][16];
+    __shared__ float coef[2][64];
+    fused_combine(s1, s2, tid, sums);
+    if (tid < 64) {
+        const int cc = blockIdx.x * 64 + tid;
+        double t1, t2;
+        fused_channel_sums(sums, tid, t1, t2);
+        const bool ok = cc < a.C;
+        const double mean = t1 / a.count;
+        double var = t2 / a.count - mean * mean;
         if (var < 0.0) var = 0.0;
         const double rstd = 1.0 / sqrt(var + (double)a.eps);
-        const double gm = (a.gamma && live) ? (double)a.gamma[c + e] : 1.0;
-        const double bt = (a.beta && live) ? (double)a.beta[c + e] : 0.0;
-        sc[e] = (float)(gm * rstd);
-        sh[e] = (float)(bt - mean * gm * rstd);
-        if (publish) {
-            const long o = (long)g * a.C + c + e;
+        const double gm = (a.gamma && ok) ? (double)a.gamma[cc] : 1.0;
+        const double bt = (a.beta && ok) ? (double)a.beta[cc] : 0.0;
+        const float fsc = (float)(gm * rstd), fsh = (float)(bt - mean * gm * rstd);
+        coef[0][tid] = fsc;
+        coef[1][tid] = fsh;
+        if (ok && chunk == 0) {
+            const long o = (long)g * a.C + cc;
             if (a.mean) a.mean[o] = (float)mean;
             if (a.rstd) a.rstd[o] = (float)rstd;
-            if (a.scale) a.scale[o] = sc[e];
-            if (a.shift) a.shift[o] = sh[e];
+            if (a.scale) a.scale[o] = fsc;
+            if (a.shift) a.shift[o] = fsh;
             if (a.running_mean) {
                 const double unb = a.count > 1.f ? var * a.count / (a.count - 1.0) : var;
-                a.running_mean[c + e] = (float)((1.0 - a.momentum) * a.running_mean[c + e] + a.momentum * mean);
-                a.running_var[c + e] = (float)((1.0 - a.momentum) * a.running_var[c + e] + a.momentum * unb);
+                a.running_mean[cc] = (float)((1.0 - a.momentum) * a.running_mean[cc] + a.momentum * mean);
+                a.running_var[cc] = (float)((1.0 - a.momentum) * a.running_var[cc] + a.momentum * unb);
             }
         }
     }
     if (a.nbt && blockIdx.x == 0 && chunk == 0 && g == 0 && tid == 0) *a.nbt += 1;
+    __syncthreads();
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = coef[0][co * 8 + e];
+        sh[e] = coef[1][co * 8 + e];
+    }
     if (!live) return;
     const long i0 = (long)chunk * a.chunk_px;
     long i1 = i0 + a.chunk_px;
@@ -406,21 +420,32 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const FusedBwdArgs 
             }
         }
     }
-    fused_combine(s1, s2, tid);
+    __shared__ double sums[4][8][16];
+    __shared__ float coef[3][64];
+    fused_combine(s1, s2, tid, sums);
+    if (tid < 64) {
+        const int cc = blockIdx.x * 64 + tid;
+        double t1, t2;
+        fused_channel_sums(sums, tid, t1, t2);
+        const bool ok = cc < a.C;
+        const double gm = (a.gamma && ok) ? (double)a.gamma[cc] : 1.0;
+        const double mean = ok ? (double)a.mean[(long)g * a.C + cc] : 0.0, rstd = ok ? (double)a.rstd[(long)g * a.C + cc] : 1.0;
+        const double m1 = t1 / a.count, m2 = t2 / a.count;
+        coef[0][tid] = (float)(gm * rstd);
+        coef[1][tid] = (float)(-gm * rstd * rstd * m2);
+        coef[2][tid] = (float)(gm * rstd * (mean * rstd * m2 - m1));
+        if (ok && chunk == 0) {
+            if (a.dgamma) a.dgamma[cc] = (float)t2;
+            if (a.dbeta) a.dbeta[cc] = (float)t1;
+        }
+    }
+    __syncthreads();
     float ka[8], kb[8], kc[8];
-    const bool publish = live && chunk == 0 && pl == 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const double gm = (a.gamma && live) ? (double)a.gamma[c + e] : 1.0;
-        const double mean = mu[e], rstd = rs[e];
-        const double m1 = s1[e] / a.count, m2 = s2[e] / a.count;
-        ka[e] = (float)(gm * rstd);
-        kb[e] = (float)(-gm * rstd * rstd * m2);
-        kc[e] = (float)(gm * rstd * (mean * rstd * m2 - m1));
-        if (publish) {
-            if (a.dgamma) a.dgamma[c + e] = (float)s2[e];
-            if (a.dbeta) a.dbeta[c + e] = (float)s1[e];
-        }
+        ka[e] = coef[0][co * 8 + e];
+        kb[e] = coef[1][co * 8 + e];
+        kc[e] = coef[2][co * 8 + e];
     }
     if (!live) return;
     const long i0 = (long)chunk * a.chunk_px;
