@@ -14,6 +14,8 @@ int conv3x3d_launch(const combat_conv_args *a, int tile, hipStream_t st);
 // DMA-staged gather-GEMM for the remaining prologue-free convolutions (conv_gather_dma.hip)
 int conv_gather_dma_bn(const combat_conv_args *a);                 // 0 (not applicable) / 64 / 32 channels per tile
 bool conv_gather_dma_parity_split(const combat_conv_args *a);      // statistics rows not image-aligned
+bool conv_c8_ok(const combat_conv_args *a);
+int conv_c8_launch(const combat_conv_args *a, hipStream_t st);
 int conv_gather_dma_launch(const combat_conv_args *a, hipStream_t st);
 long conv_gather_dma_workspace(const combat_conv_args *a);        // scratch bytes a split reduction would use
 // halo weight-gradient kernel (conv_wgrad3x3.hip): 0 launched, 1 not applicable, <0 error

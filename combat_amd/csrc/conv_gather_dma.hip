@@ -440,6 +440,97 @@ __global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_kernel(co
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv_gather_finish_kernel(const GatherParams p) { conv_gather_dma_body<BN, true, 3>(p); }
 
+// ------------------------------------------------------------------ 8-channel inputs (images, 3-channel gradients)
+// A 3x3 convolution over C = 8 (the c8 image layout; the gradient w.r.t. a 3-channel output): the whole
+// reduction is 9 taps x 8 channels = 72 <= 96 = three MFMA k-steps, and one k-block of an MFMA operand
+// (8 consecutive k of one row) is exactly one tap's eight channels of one pixel = ONE 16-byte load.  So
+// there is no staging at all: a wave's 32 pixels x 12 tap slots are six buffer loads per lane straight
+// into the B operands (padding / absent taps: out-of-range offset = zeros), the 64 x 96 weight slice is
+// twelve more, 24 MFMAs, and the shared fused epilogue.  Replaces the gather-per-tap GEMM for the stem of
+// the classifiers, the generator's first convolution and the input gradient of its last one (24-39 us ->
+// what the epilogue costs).
+template <int BN>
+__device__ __forceinline__ void conv_c8_body(const GatherParams &p) {
+    constexpr int BM = 128;
+    using T = TileCfg<BM, BN, 4>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const combat_conv_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile_m, tile_n;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tile_n = tile % p.tiles_n;
+        tile_m = tile / p.tiles_n;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int H = a.H, W = a.W;
+    const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
+    auto decode = [&](int m, int &img, int &oy, int &ox) {
+        if (p.pq_shift >= 0) {
+            img = m >> p.pq_shift;
+            const int rem = m & (p.PQ - 1);
+            oy = rem >> p.q_shift;
+            ox = rem & (a.Q - 1);
+        } else {
+            img = m / p.PQ;
+            const int rem = m - img * p.PQ;
+            oy = rem / a.Q;
+            ox = rem - oy * a.Q;
+        }
+    };
+    const int fr = lane & 15, kb = lane >> 4;
+    // weights: row n0 + i * 16 + fr, k = ks * 32 + kb * 8 (k = tap * 8 + channel; zero beyond tap 8)
+    u32x4_t fw[3][T::FN], fp[3][T::FM];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i)
+            fw[ks][i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (unsigned)(((n0 + i * 16 + fr) * a.kpad + ks * 32 + kb * 8) * 2), 0, 0);
+    // pixels: fragment j row fr = tile pixel wid * 32 + j * 16 + fr; k-block kb of k-step ks = tap ks * 4 + kb
+#pragma unroll
+    for (int j = 0; j < T::FM; ++j) {
+        const int m = m0 + wid * 32 + j * 16 + fr;
+        int img = 0, oy = 0, ox = 0;
+        if (m < p.M) decode(m, img, oy, ox);
+        const int by = a.mode == 0 ? oy * a.stride - a.pad : oy + a.pad;
+        const int bx = a.mode == 0 ? ox * a.stride - a.pad : ox + a.pad;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int tap = ks * 4 + kb, tr = (tap * 11) >> 5, ts = tap - tr * 3;
+            const int iy = a.mode == 0 ? by + tr : by - tr, ix = a.mode == 0 ? bx + ts : bx - ts;
+            const bool v = m < p.M && tap < 9 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            fp[ks][j] = __builtin_amdgcn_raw_buffer_load_b128(srsrc, v ? (unsigned)(((img * H + iy) * W + ix) * 16) : kDmaOob, 0, 0);
+        }
+    }
+    EpiRegs<T> epi;
+    epi_init<T>(epi, lane, wid, n0, [&](int row) -> long {
+        const int m = m0 + row;
+        return m < p.M ? (long)m * a.K : -1;
+    });
+    epi_fetch<T>(epi, a, p.dst_bytes, lane, n0);
+    f32x4_t acc[T::FN][T::FM];
+#pragma unroll
+    for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[ks][i]),
+                                                                    __builtin_bit_cast(bf16x8_t, fp[ks][j]), acc[i][j], 0, 0, 0);
+    epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
+                  m0 + BM > p.M, p.PQ);
+}
+
+__global__ __launch_bounds__(256, 3) void conv_c8_kernel(const GatherParams p) { conv_c8_body<64>(p); }
+
 // Workgroups per tile for a launch with `tiles` tiles and `nsteps` reduction steps: split the reduction
 // only when the tiles alone leave most of the chip idle (skinny layers: 2x2 / 4x4 feature maps).
 int pick_splits(long tiles, int nsteps) {
@@ -513,6 +604,52 @@ int launch(const combat_conv_args *a, hipStream_t st) {
 }
 
 }  // namespace
+
+// the C = 8 kernel applies: 3x3, 64-channel output tiles, forward (stride 1 / 2) or stride-1 input gradient
+bool conv_c8_ok(const combat_conv_args *a) {
+    if (a->C != 8 || a->R != 3 || a->S != 3 || (a->K & 63) || a->kpad < 96) return false;
+    if (a->pro_scale || a->pro_act || a->tanh_out || (a->mask_x && a->act_dst)) return false;
+    if (!(a->mode == 0 && (a->stride == 1 || a->stride == 2)) && !(a->mode == 1 && a->stride == 1)) return false;
+    const long big = 0x40000000L;
+    return (long)a->N * a->H * a->W * 16 < big && (long)a->rows_pad * a->kpad * 2 < big &&
+           (long)a->N * a->P * a->Q * a->K * 2 < big && a->rows_pad >= a->K;
+}
+
+int conv_c8_launch(const combat_conv_args *a, hipStream_t st) {
+    if (!conv_c8_ok(a)) return COMBAT_EINVAL;
+    GatherParams p;
+    p.a = *a;
+    p.PQ = a->P * a->Q;
+    p.M = a->N * p.PQ;
+    p.ntaps = 9;
+    p.cpt = 1;
+    p.tiles_m = (p.M + 127) / 128;
+    p.tiles_n = a->K / 64;
+    p.m_fastest = p.psplit = 0;
+    p.mq = 0;
+    p.s_shift = 0;
+    p.pq_shift = p.q_shift = -1;
+    if ((p.PQ & (p.PQ - 1)) == 0 && (a->Q & (a->Q - 1)) == 0 && a->Q >= 2 && p.PQ >= 4) {
+        p.pq_shift = __builtin_ctz(p.PQ);
+        p.q_shift = __builtin_ctz(a->Q);
+    }
+    p.src_bytes = (unsigned)((long)a->N * a->H * a->W * 16);
+    p.w_bytes = (unsigned)((long)a->rows_pad * a->kpad * 2);
+    p.dst_bytes = (unsigned)((long)p.M * a->K * 2);
+    p.splits = 1;
+    p.ws = nullptr;
+    p.stamps = nullptr;
+    constexpr int smem = EpiCfg<TileCfg<128, 64, 4>>::LDS_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_c8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_c8_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
 
 bool conv_gather_dma_parity_split(const combat_conv_args *a);
 

@@ -314,6 +314,8 @@ int pick_tile(const combat_conv_args *a) {
     if (const int halo = conv3x3_pick(a)) return halo;   // 3x3 / stride 1 with the patch held in LDS
     if ((a->tile >= COMBAT_TILE_H256x64 && a->tile < COMBAT_TILE_G128x64) || a->tile == COMBAT_TILE_D256x64)
         return 0;   // a 3x3 tile was forced but does not apply
+    if ((a->tile == 0 || a->tile == COMBAT_TILE_C8) && conv_c8_ok(a)) return COMBAT_TILE_C8;
+    if (a->tile == COMBAT_TILE_C8) return 0;
     if (a->tile == 0 || a->tile >= COMBAT_TILE_G128x64) {   // prologue-free: operands by DMA
         const int bn = conv_gather_dma_bn(a);
         if (bn) return bn == 64 ? COMBAT_TILE_G128x64 : COMBAT_TILE_G128x32;
@@ -349,6 +351,7 @@ extern "C" int combat_conv_stats_granule(int tile) {
         case COMBAT_TILE_D128x32:
         case COMBAT_TILE_G128x64:
         case COMBAT_TILE_G128x32:
+        case COMBAT_TILE_C8:
         case COMBAT_TILE_D256x64: return 32;
         case COMBAT_TILE_64x64:
         case COMBAT_TILE_64x128:
@@ -368,7 +371,9 @@ extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows
     *rows = (int)((M + gran - 1) / gran);
     *rows_per_image = (PQ % gran == 0) ? (int)(PQ / gran) : 0;
     const int bm = (tile == COMBAT_TILE_64x64 || tile == COMBAT_TILE_64x128) ? 64 : 128;
-    if (tile == COMBAT_TILE_G128x64 || tile == COMBAT_TILE_G128x32) {
+    if (tile == COMBAT_TILE_C8) {
+        // pixels in order: rows_per_image as computed
+    } else if (tile == COMBAT_TILE_G128x64 || tile == COMBAT_TILE_G128x32) {
         if (conv_gather_dma_parity_split(a)) *rows_per_image = 0;
     } else if (parity_split(*a) && (M / 4) % bm == 0) {
         *rows_per_image = 0;   // parity-class-major pixel order
@@ -407,6 +412,7 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     p.tiles_m = p.tiles_n = 0;
     hipStream_t st = as_stream(stream);
     const int tile = pick_tile(a);
+    if (tile == COMBAT_TILE_C8) return conv_c8_launch(a, st);
     if (tile == COMBAT_TILE_G128x64 || tile == COMBAT_TILE_G128x32) return conv_gather_dma_launch(a, st);
     if (tile >= COMBAT_TILE_H256x64) return conv3x3_launch(a, tile, st);
     switch (tile) {

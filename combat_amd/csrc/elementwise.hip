@@ -421,7 +421,7 @@ extern "C" int combat_pack_weights(const float *w, int32_t K, int32_t taps, int3
 extern "C" int combat_pack_weights_batch(const combat_pack_desc *descs, int32_t n, void *stream) {
     if (!descs || n < 0) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(128, (unsigned)n), dim3(256), 0, as_stream(stream), descs);
+    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(512, (unsigned)n), dim3(256), 0, as_stream(stream), descs);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

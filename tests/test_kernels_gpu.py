@@ -99,6 +99,65 @@ def test_conv3x3_halo_forward_and_dgrad(ops, n, hw, c, k, tile):
     assert rel_l2(nchw(dx), torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1)) < 4e-3
 
 
+@pytest.mark.parametrize("n,hw,k,stride", [(5, 32, 64, 1), (3, 16, 128, 1), (4, 32, 64, 2), (2, 6, 64, 1), (3, 10, 64, 2)])
+def test_conv_c8_direct_kernel(ops, n, hw, k, stride):
+    """C = 8 inputs (c8 images / 3-channel gradients): the kernel that feeds MFMA operands straight from
+    global memory must agree with the generic gather tile on the same arguments -- forward with bias,
+    residual, statistics and an activated second output; stride-1 input gradient with a per-image
+    InstanceNorm mask and the norm-backward sums -- and with torch."""
+    from combat_amd._lib import lib
+    import ctypes
+    c = 8
+    x = torch.randn(n, c, hw, hw, generator=g(201))
+    w, pc = make_conv(ops, k, c, 3, stride, 1, 202)
+    p, q = pc.out_hw(hw, hw)
+    bias = torch.randn(k, generator=g(203)) * 0.1
+    res = torch.randn(n, k, p, q, generator=g(204))
+    sc, sh = torch.rand(k, generator=g(205)) + 0.5, torch.randn(k, generator=g(206)) * 0.3
+    outs = []
+    for tile in (15, 2):
+        y = torch.empty(n, p, q, k, dtype=bf16, device="cuda")
+        act = torch.empty_like(y)
+        a = ops.conv_args(nhwc(x), y, pc, 0, bias=dev(bias), add_post=nhwc(res), stats_kind=1, tile=tile, act_dst=act,
+                          act=ops.Affine(dev(sc), dev(sh), 0, True, 0.1))
+        assert lib.combat_conv_pick_tile(ctypes.byref(a)) == tile
+        rows, rpi = ops.conv_stats_layout(a)
+        stats = torch.zeros(rows, 2, k, device="cuda")
+        a.stats = stats.data_ptr()
+        ops.conv_launch(a)
+        outs.append((y, act, stats.sum(0)))
+    assert rel_l2(outs[0][0].float(), outs[1][0].float()) < 2e-3 and rel_l2(outs[0][1].float(), outs[1][1].float()) < 2e-3
+    assert rel_l2(outs[0][2], outs[1][2]) < 1e-3
+    ref = F.conv2d(rb(x), rb(w), bias, stride=stride, padding=1) + rb(res)
+    assert rel_l2(nchw(outs[0][0]), ref) < 4e-3
+    a = ops.conv_args(nhwc(x), torch.empty(n, p, q, k, dtype=bf16, device="cuda"), pc, 0)
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) == 15          # automatic choice
+    if stride != 1:
+        return
+    # input gradient of a K = 8 convolution (here: C = k inputs, 8 outputs), per-image mask + sums
+    w2, pc2 = make_conv(ops, 8, k, 3, 1, 1, 207)
+    dy = torch.randn(n, 8, hw, hw, generator=g(208))
+    xpre = torch.randn(n, k, hw, hw, generator=g(209))
+    msc, msh = torch.rand(n, k, generator=g(210)) + 0.5, torch.randn(n, k, generator=g(211)) * 0.3
+    mean, rstd = torch.randn(n, k, generator=g(212)) * 0.1, torch.rand(n, k, generator=g(213)) + 0.5
+    outs = []
+    for tile in (15, 2):
+        dx = torch.empty(n, hw, hw, k, dtype=bf16, device="cuda")
+        a = ops.conv_args(nhwc(dy), dx, pc2, 1, mask_x=nhwc(xpre), mask=ops.Affine(dev(msc), dev(msh), k, True, 0.2),
+                          stats_kind=2, xh_mean=dev(mean), xh_rstd=dev(rstd), tile=tile)
+        assert lib.combat_conv_pick_tile(ctypes.byref(a)) == tile
+        rows, rpi = ops.conv_stats_layout(a)
+        stats = torch.zeros(rows, 2, k, device="cuda")
+        a.stats = stats.data_ptr()
+        ops.conv_launch(a)
+        outs.append((dx, stats.sum(0), rpi))
+    assert rel_l2(outs[0][0].float(), outs[1][0].float()) < 2e-3 and rel_l2(outs[0][1], outs[1][1]) < 2e-3
+    assert outs[0][2] == outs[1][2]
+    gin = torch.nn.grad.conv2d_input((n, k, hw, hw), rb(w2), rb(dy), padding=1)
+    keep = (rb(xpre) * msc[:, :, None, None] + msh[:, :, None, None]) > 0
+    assert rel_l2(nchw(outs[0][0]), torch.where(keep, gin, 0.2 * gin)) < 4e-3
+
+
 DMA_CASES = [
     # n, hw, c, k, tile   (prologue-free 3x3 convolutions with both operands DMA'd into LDS)
     (4, 32, 64, 64, 10), (2, 32, 128, 128, 10), (3, 16, 128, 128, 10), (5, 16, 64, 128, 10), (3, 16, 256, 64, 10),
