@@ -55,7 +55,8 @@ class PackDesc(C.Structure):
 
     _fields_ = [("w", c_vp), ("wf", c_vp), ("wd", c_vp),
                 ("K", c_i32), ("taps", c_i32), ("c_real", c_i32), ("C", c_i32), ("dup_hilo", c_i32),
-                ("rows_pad_f", c_i32), ("kpad_f", c_i32), ("rows_pad_d", c_i32), ("kpad_d", c_i32), ("reserved", c_i32)]
+                ("rows_pad_f", c_i32), ("kpad_f", c_i32), ("rows_pad_d", c_i32), ("kpad_d", c_i32), ("reserved", c_i32),
+                ("row_scale", c_vp)]
 
 
 class BnDesc(C.Structure):
@@ -90,6 +91,8 @@ SIGNATURES = {
     "combat_norm_bwd_apply": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "combat_norm_act_fused": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "combat_norm_add_act_fused": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                            c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "combat_norm_bwd_fused": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                         c_vp, c_i64, c_vp, c_vp]),
     "combat_group_stats_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
@@ -108,6 +111,7 @@ SIGNATURES = {
     "combat_nhwc_to_nchw_f32": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_nchw_to_nhwc_bf16": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_memset_zero": (C.c_int, [c_vp, c_i64, c_vp]),
+    "combat_relu_mask": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "combat_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "combat_maxpool2": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_elu_affine": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),

@@ -46,13 +46,21 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const combat_pa
     __bf16 *__restrict__ wf = reinterpret_cast<__bf16 *>(d.wf);
     __bf16 *__restrict__ wd = reinterpret_cast<__bf16 *>(d.wd);
     const int K = d.K, taps = d.taps, creal = d.c_real, C = d.C, Kc = (d.K + 7) & ~7;
+    const float *__restrict__ rs = d.row_scale;
     const long nf = (long)d.rows_pad_f * d.kpad_f;
     if (creal == C && !d.dup_hilo && d.kpad_f == taps * C) {
         // forward layout == the master's layout: a streaming fp32 -> bf16 conversion, 8 elements per thread
         const long nreal = (long)K * d.kpad_f;   // rows >= K are zero padding
         for (long t8 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; t8 < nf; t8 += (long)gridDim.x * blockDim.x * 8) {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (t8 < nreal) load8f(w + t8, v);
+            if (t8 < nreal) {
+                load8f(w + t8, v);
+                if (rs) {
+                    const float f = rs[t8 / d.kpad_f];   // kpad is a multiple of 8: the eight share a row
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= f;
+                }
+            }
             *reinterpret_cast<uint4 *>(wf + t8) = pack8(v);
         }
     } else {
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const combat_pa
                 int cm = -1;
                 if (c < creal) cm = c;
                 else if (d.dup_hilo && c < 2 * creal) cm = c - creal;
-                if (cm >= 0) v = w[((long)n * taps + tap) * creal + cm];
+                if (cm >= 0) v = w[((long)n * taps + tap) * creal + cm] * (rs ? rs[n] : 1.f);
             }
             wf[t] = (__bf16)v;
         }
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const combat_pa
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int kl = ty + 8 * it, k = k0 + kl, tap = k / Kc, n = k - tap * Kc, c = c0 + tx;
-            tile[kl][tx] = (c < creal && tap < taps && n < K) ? w[((long)n * taps + tap) * creal + c] : 0.f;
+            tile[kl][tx] = (c < creal && tap < taps && n < K) ? w[((long)n * taps + tap) * creal + c] * (rs ? rs[n] : 1.f) : 0.f;
         }
         __syncthreads();
 #pragma unroll
@@ -488,6 +496,30 @@ extern "C" int combat_elu_affine(const void *x, int64_t rows, int32_t C, const f
     hipLaunchKernelGGL(elu_affine_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), (long)rows, C, scale, shift,
                        reinterpret_cast<__bf16 *>(out));
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+namespace {
+// out = act > 0 ? g : 0  (gradient through the ReLU that produced `act`), 8 bf16 per thread
+__global__ __launch_bounds__(256) void relu_mask_kernel(const uint4 *__restrict__ g, const uint4 *__restrict__ act,
+                                                        long n8, uint4 *__restrict__ out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += (long)gridDim.x * blockDim.x) {
+        float gv[8], av[8];
+        unpack8(g[t], gv);
+        unpack8(act[t], av);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = av[e] > 0.f ? gv[e] : 0.f;
+        out[t] = pack8(gv);
+    }
+}
+}  // namespace
+
+extern "C" int combat_relu_mask(const void *g, const void *act, int64_t elements, void *out, void *stream) {
+    if (!g || !act || !out || elements <= 0 || (elements & 7)) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(elements / 8, 8192)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const uint4 *>(g), reinterpret_cast<const uint4 *>(act), (long)(elements / 8),
+                       reinterpret_cast<uint4 *>(out));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

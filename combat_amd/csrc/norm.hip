@@ -262,6 +262,8 @@ struct FusedFwdArgs {
     float *mean, *rstd, *scale, *shift, *running_mean, *running_var;
     float momentum;
     int64_t *nbt;
+    const __bf16 *add;                     // optional residual: act = lrelu(x*scale + shift + (add*add_scale + add_shift))
+    const float *add_scale, *add_shift;    // per channel (NULL: 1 / 0): the shortcut's own, already finalised BatchNorm
 };
 
 __global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs a) {
@@ -346,15 +348,30 @@ __global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs 
     const long i0 = (long)chunk * a.chunk_px;
     long i1 = i0 + a.chunk_px;
     if (i1 > a.pxg) i1 = a.pxg;
+    float asc[8], ash[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        asc[e] = 1.f;
+        ash[e] = 0.f;
+    }
+    if (a.add && a.add_scale) {
+        load8f(a.add_scale + c, asc);
+        load8f(a.add_shift + c, ash);
+    }
     for (long i = i0 + pl; i < i1; i += 32) {
         const long off = ((long)g * a.pxg + i) * a.C + c;
         float v[8];
         unpack8(*reinterpret_cast<const uint4 *>(a.x + off), v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = fmaf(v[e], sc[e], sh[e]);
-            v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        if (a.add) {
+            float r[8];
+            unpack8(*reinterpret_cast<const uint4 *>(a.add + off), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += fmaf(r[e], asc[e], ash[e]);
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
         *reinterpret_cast<uint4 *>(a.act + off) = pack8(v);
     }
 }
@@ -544,16 +561,17 @@ extern "C" int combat_norm_bwd_finalize(const float *partials, int32_t groups, i
     return COMBAT_OK;
 }
 
-extern "C" int combat_norm_act_fused(const void *x, const float *partials, int32_t groups, int32_t rows_per_group,
-                                     int64_t px_per_group, int32_t C, float eps, float slope, const float *gamma,
-                                     const float *beta, float *mean, float *rstd, float *scale, float *shift,
-                                     float *running_mean, float *running_var, float momentum,
-                                     int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes, void *act,
-                                     void *stream) {
+static int norm_act_fused_launch(const void *x, const float *partials, int32_t groups, int32_t rows_per_group,
+                                 int64_t px_per_group, int32_t C, float eps, float slope, const float *gamma,
+                                 const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                                 float *running_mean, float *running_var, float momentum,
+                                 int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes, const void *add,
+                                 const float *add_scale, const float *add_shift, void *act, void *stream) {
     if (!x || !act || groups <= 0 || px_per_group <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     if (partials ? rows_per_group <= 0 : px_per_group > kFusedMaxDirect) return COMBAT_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return COMBAT_EINVAL;
     if (running_mean && groups != 1) return COMBAT_EINVAL;
+    if ((add_scale == nullptr) != (add_shift == nullptr) || (add_scale && (!add || groups != 1))) return COMBAT_EINVAL;
     hipStream_t st = as_stream(stream);
     int rpg = partials ? rows_per_group : 0;
     const float *src = partials;
@@ -565,11 +583,36 @@ extern "C" int combat_norm_act_fused(const void *x, const float *partials, int32
     const int chunk = partials ? fused_chunk(px_per_group, groups, C) : (int)px_per_group;
     FusedFwdArgs a{reinterpret_cast<const __bf16 *>(x), reinterpret_cast<__bf16 *>(act), src, rpg, C,
                    (long)px_per_group, chunk, (float)px_per_group, eps, slope, gamma, beta, mean, rstd, scale, shift,
-                   running_mean, running_var, momentum, num_batches_tracked};
+                   running_mean, running_var, momentum, num_batches_tracked, reinterpret_cast<const __bf16 *>(add),
+                   add_scale, add_shift};
     hipLaunchKernelGGL(norm_act_fused_kernel,
                        dim3((C + 63) / 64, (unsigned)((px_per_group + chunk - 1) / chunk), groups), dim3(256), 0, st, a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
+}
+
+extern "C" int combat_norm_act_fused(const void *x, const float *partials, int32_t groups, int32_t rows_per_group,
+                                     int64_t px_per_group, int32_t C, float eps, float slope, const float *gamma,
+                                     const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                                     float *running_mean, float *running_var, float momentum,
+                                     int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes, void *act,
+                                     void *stream) {
+    return norm_act_fused_launch(x, partials, groups, rows_per_group, px_per_group, C, eps, slope, gamma, beta, mean, rstd,
+                                 scale, shift, running_mean, running_var, momentum, num_batches_tracked, scratch,
+                                 scratch_bytes, nullptr, nullptr, nullptr, act, stream);
+}
+
+extern "C" int combat_norm_add_act_fused(const void *x, const float *partials, int32_t groups, int32_t rows_per_group,
+                                         int64_t px_per_group, int32_t C, float eps, float slope, const float *gamma,
+                                         const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                                         float *running_mean, float *running_var, float momentum,
+                                         int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes,
+                                         const void *add, const float *add_scale, const float *add_shift, void *act,
+                                         void *stream) {
+    if (!add) return COMBAT_EINVAL;
+    return norm_act_fused_launch(x, partials, groups, rows_per_group, px_per_group, C, eps, slope, gamma, beta, mean, rstd,
+                                 scale, shift, running_mean, running_var, momentum, num_batches_tracked, scratch,
+                                 scratch_bytes, add, add_scale, add_shift, act, stream);
 }
 
 extern "C" int combat_norm_bwd_fused(const void *dz, const void *x, const void *add, const float *partials,

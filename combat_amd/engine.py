@@ -320,8 +320,8 @@ class NetEngine:
             self.slots[key] = s
         return s
 
-    def _pc(self, weight, stride, pad, cin_pad, dup=False, need_dgrad=True) -> PackedConv:
-        pc = PackedConv(weight, stride, pad, cin_pad, dup_hilo=dup, need_dgrad=need_dgrad)
+    def _pc(self, weight, stride, pad, cin_pad, dup=False, need_dgrad=True, row_scale=None) -> PackedConv:
+        pc = PackedConv(weight, stride, pad, cin_pad, dup_hilo=dup, need_dgrad=need_dgrad, row_scale=row_scale)
         self.convs.append(pc)
         return pc
 
@@ -346,10 +346,7 @@ class NetEngine:
             from ._lib import PackDesc
             tab = (PackDesc * len(self.convs))()
             for d, pc, m in zip(tab, self.convs, masters):
-                d.w, d.wf, d.wd = m.data_ptr(), pc.wf.data_ptr(), (pc.wd.data_ptr() if pc.wd is not None else None)
-                d.K, d.taps, d.c_real, d.C, d.dup_hilo = pc.K, pc.taps, pc.c_real, pc.C, int(pc.dup_hilo)
-                d.rows_pad_f, d.kpad_f = pc.rows_f, pc.kpad_f
-                d.rows_pad_d, d.kpad_d = (pc.rows_d, pc.kpad_d) if pc.wd is not None else (0, 0)
+                pc.fill_desc(d, m)
             self._pack_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
             self._pack_ptrs = ptrs
         ops.check(lib.combat_pack_weights_batch(self._pack_tab.data_ptr(), len(self.convs),
@@ -757,6 +754,227 @@ class PreActEngine(NetEngine):
         return P
 
 
+class ResNetEngine(PreActEngine):
+    """ResNet18 (classifier_models/resnet.py:15-37, 68-106; the CelebA classifier): post-activation
+    BasicBlocks  out = relu(bn2(conv2(relu(bn1(conv1(x))))) + shortcut(x)),  shortcut = conv1x1 + BatchNorm
+    where the shape changes, stem conv + BatchNorm + ReLU, avg_pool2d(4) + Linear.
+
+    A BatchNorm here FOLLOWS its convolution, so
+      * eval mode: bn1 / the stem's norm are the producing convolution's activated-output epilogue, as in
+        the pre-activation net; bn2 and the shortcut's norm sit in front of the residual sum and are folded
+        into the packed weights (row_scale = gamma * rstd, the shift travels as the bias): every block is
+        three launches and no tensor is stored raw;
+      * train mode: batch statistics from the conv epilogues; bn2 + residual (+ the shortcut's own,
+        separately finalised norm) + ReLU are one fused launch (combat_norm_add_act_fused).
+    Tensors: 'stem.a' = relu(bn(conv(x))), 'b%d.a1' = relu(bn1(conv1(.))), 'b%d.out' = the block output
+    (activated); train only: raw 'stem', 'b%d.y1', 'b%d.y2', 'b%d.ys' for the norm backward passes."""
+
+    def __init__(self, module):
+        NetEngine.__init__(self, module)
+        m = module
+        self.classes = m.linear.out_features
+        self.stem = self._pc(m.conv1.weight.data, 1, 1, 8, dup=True)
+        self.bn0 = _BN(self, m.bn1, "bn1")
+        self.blocks: List[_Blk] = []
+        self.bns: List[_BN] = [self.bn0]
+        for li in range(1, 5):
+            for bi, blk in enumerate(getattr(m, "layer%d" % li)):
+                e = _Blk()
+                e.prefix = "layer%d.%d." % (li, bi)
+                e.stride, e.cin, e.planes = blk.stride, blk.conv1.in_channels, blk.conv1.out_channels
+                e.bn1, e.bn2 = _BN(self, blk.bn1, e.prefix + "bn1"), _BN(self, blk.bn2, e.prefix + "bn2")
+                e.conv1 = self._pc(blk.conv1.weight.data, blk.stride, 1, e.cin)
+                e.conv2 = self._pc(blk.conv2.weight.data, 1, 1, e.planes)
+                e.conv2e = self._pc(blk.conv2.weight.data, 1, 1, e.planes, row_scale=e.bn2.escale)
+                e.sc = e.sce = e.bns = None
+                if len(blk.shortcut):      # (an empty nn.Sequential for identity shortcuts, resnet.py:24)
+                    e.bns = _BN(self, blk.shortcut[1], e.prefix + "shortcut.1")
+                    e.sc = self._pc(blk.shortcut[0].weight.data, blk.stride, 0, e.cin)
+                    e.sce = self._pc(blk.shortcut[0].weight.data, blk.stride, 0, e.cin, row_scale=e.bns.escale)
+                    self.bns.append(e.bns)
+                self.blocks.append(e)
+                self.bns += [e.bn1, e.bn2]
+        self.lin_w, self.lin_b = m.linear.weight.data, m.linear.bias.data
+        self.ones = torch.ones(512, dtype=f32, device=self.device)
+        self.zeros = torch.zeros(512, dtype=f32, device=self.device)
+
+    def refresh(self) -> None:
+        """The folded eval operands read the eval scale of their BatchNorm: fold first, then pack."""
+        if not self.weights_dirty:
+            return
+        self.fold_bn()
+        self._pack_all()
+        self.weights_dirty = False
+
+    FWD_SHARED = ("stem.a", "logits", "dlogits", "pooled", "targets", "targets2") + tuple(
+        "b%d.%s" % (b, s) for b in range(8) for s in ("a1", "out", "scv"))
+
+    def _block_in(self, slot: Slot, b: int):
+        return slot.bufs["stem.a"] if b == 0 else slot.bufs["b%d.out" % (b - 1)]
+
+    # ---- forward
+    def _forward_eval_body(self, P: Plan, slot: Slot, x):
+        n, hw = slot.N, slot.hw
+        cur = slot.buf("stem.a", (n, hw, hw, 64))
+        rec_conv(P, "stem", x, None, self.stem, 0, act_dst=cur, act=self.bn0.eval_affine())
+        relu = Affine(self.ones, self.zeros, 0, True, 0.0)
+        chw = hw
+        for b, blk in enumerate(self.blocks):
+            ohw = chw // blk.stride
+            shape = (n, ohw, ohw, blk.planes)
+            a1 = slot.buf("b%d.a1" % b, shape)
+            rec_conv(P, "b%d.c1" % b, cur, None, blk.conv1, 0, act_dst=a1, act=blk.bn1.eval_affine())
+            if blk.sc is not None:
+                resid = slot.buf("b%d.scv" % b, shape)
+                rec_conv(P, "b%d.sc" % b, cur, resid, blk.sce, 0, bias=blk.bns.eshift)
+            else:
+                resid = cur
+            out = slot.buf("b%d.out" % b, shape)
+            rec_conv(P, "b%d.c2" % b, a1, None, blk.conv2e, 0, bias=blk.bn2.eshift, add_post=resid, act_dst=out, act=relu)
+            cur, chw = out, ohw
+        return cur, chw
+
+    def _norm_add_act(self, plan: Plan, st: NormState, act_dst, add, add_scale, add_shift):
+        q = st.pending
+        st.pending = None
+        x = q["x"]
+        plan.hold(x, act_dst, q["part"], add, add_scale, add_shift)
+        plan.add(q["key"] + ".finaddact", lib.combat_norm_add_act_fused, x.data_ptr(), _p(q["part"]), st.groups, q["rpg"],
+                 q["pxg"], st.C, 1e-5, 0.0, _p(q["gamma"]), _p(q["beta"]), st.mean.data_ptr(), st.rstd.data_ptr(),
+                 st.scale.data_ptr(), st.shift.data_ptr(), _p(q["rm"]), _p(q["rv"]), 0.1, _p(q["nbt"]),
+                 self._scratch.data_ptr(), self._scratch.numel() * 4, add.data_ptr(), _p(add_scale), _p(add_shift),
+                 act_dst.data_ptr())
+
+    def _forward_train_body(self, P: Plan, slot: Slot, x):
+        n, hw = slot.N, slot.hw
+        bnk = lambda bn: dict(gamma=bn.gamma, beta=bn.beta, running=(bn.rm, bn.rv, bn.nbt))
+        y0 = slot.buf("stem", (n, hw, hw, 64))
+        cur = slot.buf("stem.a", y0.shape)
+        self._conv_norm(P, slot, self.bn0.prefix, x, y0, self.stem, groups=1, act_dst=cur, **bnk(self.bn0))
+        chw = hw
+        for b, blk in enumerate(self.blocks):
+            ohw = chw // blk.stride
+            shape = (n, ohw, ohw, blk.planes)
+            y1, a1 = slot.buf("b%d.y1" % b, shape), slot.buf("b%d.a1" % b, shape)
+            self._conv_norm(P, slot, blk.bn1.prefix, cur, y1, blk.conv1, groups=1, act_dst=a1, **bnk(blk.bn1))
+            y2 = slot.buf("b%d.y2" % b, shape)
+            st2 = self._conv_norm(P, slot, blk.bn2.prefix, a1, y2, blk.conv2, groups=1, defer=True, **bnk(blk.bn2))
+            out = slot.buf("b%d.out" % b, shape)
+            if blk.sc is not None:
+                ys = slot.buf("b%d.ys" % b, shape)
+                sts = self._conv_norm(P, slot, blk.bns.prefix, cur, ys, blk.sc, groups=1, **bnk(blk.bns))
+                self._norm_add_act(P, st2, out, ys, sts.scale, sts.shift)
+            else:
+                self._norm_add_act(P, st2, out, cur, None, None)
+            cur, chw = out, ohw
+        return cur, chw
+
+    # ---- backward
+    def _head_grad(self, P: Plan, slot: Slot, loss_weight: float, train: bool):
+        """Gradient w.r.t. the last block's output, through its ReLU."""
+        fp, n = self.fp, slot.N
+        h = self.head_bufs(slot)
+        feat = slot.bufs["b%d.out" % (len(self.blocks) - 1)]
+        d_feat = slot.buf("g.feat", feat.shape)
+        P.add("head_bwd", lib.combat_head_bwd, h["pooled"].data_ptr() if train else None, n, slot.feat_hw, feat.shape[-1],
+              self.lin_w.data_ptr(), self.classes, h["logits"].data_ptr(), h["targets"].data_ptr(), loss_weight,
+              h["dlogits"].data_ptr(), d_feat.data_ptr(), fp.grad_phys("linear.weight").data_ptr() if train else None,
+              fp.grad_phys("linear.bias").data_ptr() if train else None)
+        d_out = slot.buf("g.feat.m", feat.shape)
+        P.add("head_bwd.relu", lib.combat_relu_mask, d_feat.data_ptr(), feat.data_ptr(), feat.numel(), d_out.data_ptr())
+        return d_out
+
+    def backward_train_plan(self, slot: Slot, loss_weight: float = 1.0) -> Plan:
+        key = "bwd.train.%g" % loss_weight
+        if key in slot.plans:
+            return slot.plans[key]
+        P = Plan("resnet." + key)
+        fp = self.fp
+        G = lambda name, like: slot.buf("g." + name, like.shape)
+        P.add("zero_grad", lib.combat_memset_zero, fp.grad.data_ptr(), fp.total * 4)
+        d_out = self._head_grad(P, slot, loss_weight, True)
+
+        def bn_bwd(bn, key_, dz, x_pre, name):
+            """BatchNorm backward of dz w.r.t. the raw tensor x_pre (sums taken from the tensors)."""
+            st = slot.norm[bn.prefix]
+            st.bpending = dict(part=None, rpg=0, gamma=bn.gamma, dgamma=fp.grad_phys(bn.prefix + ".weight"),
+                               dbeta=fp.grad_phys(bn.prefix + ".bias"))
+            dx = G(name, x_pre)
+            self._bwd_apply(P, slot, key_, dz, x_pre, dx, st)
+            return dx
+
+        for b in reversed(range(len(self.blocks))):
+            blk, pre = self.blocks[b], self.blocks[b].prefix
+            cur_in = self._block_in(slot, b)
+            y1, a1, y2 = slot.bufs["b%d.y1" % b], slot.bufs["b%d.a1" % b], slot.bufs["b%d.y2" % b]
+            dy2 = bn_bwd(blk.bn2, "g." + blk.bn2.prefix, d_out, y2, "b%d.dy2" % b)
+            tsc = None
+            if blk.sc is not None:
+                dys = bn_bwd(blk.bns, "g." + blk.bns.prefix, d_out, slot.bufs["b%d.ys" % b], "b%d.dys" % b)
+                rec_wgrad(P, "b%d.sc.wgrad" % b, cur_in, dys, blk.sc, fp.grad_phys(pre + "shortcut.0.weight"))
+                tsc = G("b%d.tsc" % b, cur_in)
+                rec_conv(P, "b%d.sc.dgrad" % b, dys, tsc, blk.sc, 1)
+            rec_wgrad(P, "b%d.c2.wgrad" % b, a1, dy2, blk.conv2, fp.grad_phys(pre + "conv2.weight"))
+            st1 = slot.norm[blk.bn1.prefix]
+            dz1 = G("b%d.dz1" % b, y1)
+            self._dgrad_norm(P, slot, "g." + blk.bn1.prefix, dy2, dz1, blk.conv2, y1, st1, group_stride=0, slope=0.0,
+                             gamma=blk.bn1.gamma, dgamma=fp.grad_phys(pre + "bn1.weight"),
+                             dbeta=fp.grad_phys(pre + "bn1.bias"))
+            dy1 = G("b%d.dy1" % b, y1)
+            self._bwd_apply(P, slot, "g." + blk.bn1.prefix, dz1, y1, dy1, st1)
+            rec_wgrad(P, "b%d.c1.wgrad" % b, cur_in, dy1, blk.conv1, fp.grad_phys(pre + "conv1.weight"))
+            other = tsc if blk.sc is not None else d_out        # the shortcut's share of the block-input gradient
+            if b > 0:   # through the previous block's final ReLU
+                dxin = G("b%d.dx" % b, cur_in)
+                rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=other, mask_x=cur_in, mask_activated=True)
+                d_out = dxin
+                if b in (6, 4, 2):
+                    P.mark(fp.offsets[pre + "conv1.weight"][0])
+            else:       # into the stem: ReLU + BatchNorm of the raw stem output
+                y0, st0 = slot.bufs["stem"], slot.norm[self.bn0.prefix]
+                dz0 = G("stem.dz", y0)
+                self._dgrad_norm(P, slot, "g." + self.bn0.prefix, dy1, dz0, blk.conv1, y0, st0, group_stride=0, slope=0.0,
+                                 gamma=self.bn0.gamma, dgamma=fp.grad_phys("bn1.weight"), dbeta=fp.grad_phys("bn1.bias"),
+                                 add_pre=other)
+                dy0 = G("stem.dy", y0)
+                self._bwd_apply(P, slot, "g." + self.bn0.prefix, dz0, y0, dy0, st0)
+                rec_wgrad(P, "stem.wgrad", self.input(slot), dy0, self.stem, fp.grad_phys("conv1.weight"))
+        P.mark(0)
+        slot.plans[key] = P
+        return P
+
+    def backward_eval_plan(self, slot: Slot, loss_weight: float) -> Plan:
+        """Input gradient of an eval-mode forward (result: 'g.img'); masks from the activated tensors, the
+        BatchNorm scales from the folded operands (bn2, shortcut) or the mask tables (bn1, stem)."""
+        key = "bwd.eval.%g" % loss_weight
+        if key in slot.plans:
+            return slot.plans[key]
+        P = Plan("resnet." + key)
+        n = slot.N
+        d_out = self._head_grad(P, slot, loss_weight, False)
+        for b in reversed(range(len(self.blocks))):
+            blk = self.blocks[b]
+            cur_in, a1 = self._block_in(slot, b), slot.bufs["b%d.a1" % b]
+            dy1 = slot.buf("g.b%d.dy1" % b, a1.shape)
+            rec_conv(P, "b%d.c2.dgrad" % b, d_out, dy1, blk.conv2e, 1, mask_x=a1, mask=blk.bn1.eval_affine(),
+                     mask_mul_scale=True, mask_activated=True)
+            other = d_out
+            if blk.sc is not None:
+                other = slot.buf("g.b%d.tsc" % b, cur_in.shape)
+                rec_conv(P, "b%d.sc.dgrad" % b, d_out, other, blk.sce, 1)
+            dxin = slot.buf("g.b%d.dx" % b, cur_in.shape)
+            if b > 0:
+                rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=other, mask_x=cur_in, mask_activated=True)
+            else:
+                rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=other, mask_x=cur_in,
+                         mask=self.bn0.eval_affine(), mask_mul_scale=True, mask_activated=True)
+            d_out = dxin
+        gimg = slot.buf("g.img", (n, slot.hw, slot.hw, 8))
+        rec_conv(P, "stem.dgrad", d_out, gimg, self.stem, 1)
+        slot.plans[key] = P
+        return P
+
+
 # --------------------------------------------------------------------------------------------
 # UNet generator
 # --------------------------------------------------------------------------------------------
@@ -993,7 +1211,7 @@ class FreqEngine(NetEngine):
 # drop-in module(x) with autograd (reference call signature; not the fast path)
 # --------------------------------------------------------------------------------------------
 
-ENGINES = {"preact_resnet18": PreActEngine, "unet": UnetEngine, "freq": FreqEngine}
+ENGINES = {"preact_resnet18": PreActEngine, "resnet18": ResNetEngine, "unet": UnetEngine, "freq": FreqEngine}
 
 
 def build_engine(module) -> NetEngine:

@@ -54,8 +54,11 @@ class PackedConv:
     order is [K][R][S][c_real]); ``pack()`` re-derives the bf16 operands after an update."""
 
     def __init__(self, weight: torch.Tensor, stride: int, pad: int, c_in_padded: int, dup_hilo: bool = False,
-                 need_dgrad: bool = True):
+                 need_dgrad: bool = True, row_scale: Optional[torch.Tensor] = None):
+        """row_scale ([K] fp32, device): pack row_scale[n] * w[n] -- an eval-mode BatchNorm that follows the
+        convolution, folded into the operands (re-read at every pack)."""
         k, c_real, r, s = weight.shape
+        self.row_scale = row_scale
         assert r == s
         self.weight = weight
         self.K, self.c_real, self.R, self.stride, self.pad = k, c_real, r, stride, pad
@@ -77,8 +80,24 @@ class PackedConv:
         w = self.weight.detach()
         return w.permute(0, 2, 3, 1).contiguous() if not w.permute(0, 2, 3, 1).is_contiguous() else w.permute(0, 2, 3, 1)
 
+    def fill_desc(self, d, master: torch.Tensor) -> None:
+        """combat_pack_desc of this convolution (`master` = self.master(), kept alive by the caller)."""
+        d.w, d.wf, d.wd = master.data_ptr(), self.wf.data_ptr(), (self.wd.data_ptr() if self.wd is not None else None)
+        d.K, d.taps, d.c_real, d.C, d.dup_hilo = self.K, self.taps, self.c_real, self.C, int(self.dup_hilo)
+        d.rows_pad_f, d.kpad_f = self.rows_f, self.kpad_f
+        d.rows_pad_d, d.kpad_d = (self.rows_d, self.kpad_d) if self.wd is not None else (0, 0)
+        d.row_scale = _p(self.row_scale)
+
     def pack(self) -> None:
         w = self.master()
+        if self.row_scale is not None:   # the scaled form exists as a batch descriptor only
+            from ._lib import PackDesc
+            tab = (PackDesc * 1)()
+            self.fill_desc(tab[0], w)
+            dtab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.weight.device)
+            check(lib.combat_pack_weights_batch(dtab.data_ptr(), 1, _stream()), "combat_pack_weights_batch")
+            torch.cuda.current_stream().synchronize()   # (dtab must outlive the launch)
+            return
         check(lib.combat_pack_weights(w.data_ptr(), self.K, self.taps, self.c_real, self.C, int(self.dup_hilo),
                                       self.wf.data_ptr(), self.rows_f, self.kpad_f, _p(self.wd), self.rows_d,
                                       self.kpad_d, _stream()),

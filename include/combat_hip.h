@@ -189,6 +189,9 @@ typedef struct combat_pack_desc {
     void *wf, *wd;
     int32_t K, taps, c_real, C, dup_hilo, rows_pad_f, kpad_f, rows_pad_d, kpad_d;
     int32_t reserved;
+    const float *row_scale;   /* NULL, or [K]: output channel n is packed as row_scale[n] * w[n] -- an eval-mode
+                               * BatchNorm that FOLLOWS the convolution folded into its weights (post-activation
+                               * ResNet blocks, classifier_models/resnet.py:27-33: relu(bn2(conv2(.)) + shortcut)) */
 } combat_pack_desc;
 int combat_pack_weights_batch(const combat_pack_desc *descs, int32_t n, void *stream);
 
@@ -261,6 +264,16 @@ int combat_norm_act_fused(const void *x, const float *partials, int32_t groups, 
                           const float *beta, float *mean, float *rstd, float *scale, float *shift,
                           float *running_mean, float *running_var, float momentum, int64_t *num_batches_tracked,
                           float *scratch, int64_t scratch_bytes, void *act, void *stream);
+/* combat_norm_act_fused with a residual operand (post-activation ResNet blocks in train mode,
+ * classifier_models/resnet.py:27-33): act = lrelu(x*scale + shift + (add*add_scale[c] + add_shift[c]), slope);
+ * add_scale / add_shift NULL: the residual is added as is (identity shortcut); given: the shortcut's own
+ * BatchNorm, finalised before this call (groups must be 1). */
+int combat_norm_add_act_fused(const void *x, const float *partials, int32_t groups, int32_t rows_per_group,
+                              int64_t px_per_group, int32_t C, float eps, float slope, const float *gamma,
+                              const float *beta, float *mean, float *rstd, float *scale, float *shift,
+                              float *running_mean, float *running_var, float momentum,
+                              int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes, const void *add,
+                              const float *add_scale, const float *add_shift, void *act, void *stream);
 int combat_norm_bwd_fused(const void *dz, const void *x, const void *add, const float *partials, int32_t groups,
                           int32_t rows_per_group, int64_t px_per_group, int32_t C, const float *gamma,
                           const float *mean, const float *rstd, float *dgamma, float *dbeta, float *scratch,
@@ -359,6 +372,9 @@ int combat_nhwc_to_nchw_f32(const void *x, int32_t n, int32_t h, int32_t w, int3
 /* fp32 NCHW -> bf16 NHWC with C padded to a multiple of 8 */
 int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t C, void *out,
                              void *stream);
+/* out = act > 0 ? g : 0 over `elements` bf16 (a multiple of 8): the gradient through the final ReLU of a
+ * post-activation block whose consumer is not a convolution (the head; classifier_models/resnet.py:33,99) */
+int combat_relu_mask(const void *g, const void *act, int64_t elements, void *out, void *stream);
 /* hipMemsetAsync(ptr, 0, bytes): gradient buffers are accumulated into and must start at zero */
 int combat_memset_zero(void *ptr, int64_t bytes, void *stream);
 /* column sums of a bf16 [rows][C] tensor into fp32 out[c_out] (overwritten): conv bias gradient */

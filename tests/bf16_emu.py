@@ -65,6 +65,58 @@ def preact_forward_emu(p, x, train, force=None):
     return F.linear(feat, p["linear.weight"], p["linear.bias"])
 
 
+def _bn_eval_tables(p, name, eps=1e-5):
+    scale = p[name + ".weight"] / torch.sqrt(p[name + ".running_var"] + eps)
+    return scale, p[name + ".bias"] - p[name + ".running_mean"] * scale
+
+
+def resnet_forward_emu(p, x, train, force=None):
+    """ResNet18 (post-activation BasicBlocks) as combat_amd.engine.ResNetEngine computes it.  Train mode:
+    raw conv outputs stored in bf16, batch statistics from them, relu(bn(.)) (+ residual) stored in bf16.
+    Eval mode: bn1 / stem norm applied to the bf16-rounded conv output by the producer's epilogue; bn2 and
+    the shortcut norm folded into bf16 operands (rounding of scale * w), their shifts added as biases."""
+    f = force
+    if train:
+        y0 = q(F.conv2d(x, qw(p, "conv1.weight"), padding=1), f, "stem")
+        cur = q(F.relu(_bn_affine(p, "bn1", y0, True)), f, "stem.a")
+    else:
+        s0, t0 = _bn_eval_tables(p, "bn1")
+        y0 = q(F.conv2d(x, qw(p, "conv1.weight"), padding=1))
+        cur = q(F.relu(y0 * s0.view(1, -1, 1, 1) + t0.view(1, -1, 1, 1)), f, "stem.a")
+    b = 0
+    for layer, stride0 in ((1, 1), (2, 2), (3, 2), (4, 2)):
+        for blk in (0, 1):
+            pre = "layer%d.%d." % (layer, blk)
+            stride = stride0 if blk == 0 else 1
+            sck = pre + "shortcut.0.weight"
+            if train:
+                y1 = q(F.conv2d(cur, qw(p, pre + "conv1.weight"), stride=stride, padding=1), f, "b%d.y1" % b)
+                a1 = q(F.relu(_bn_affine(p, pre + "bn1", y1, True)), f, "b%d.a1" % b)
+                y2 = q(F.conv2d(a1, qw(p, pre + "conv2.weight"), padding=1), f, "b%d.y2" % b)
+                if sck in p:
+                    ys = q(F.conv2d(cur, qw(p, sck), stride=stride), f, "b%d.ys" % b)
+                    scv = _bn_affine(p, pre + "shortcut.1", ys, True)
+                else:
+                    scv = cur
+                cur = q(F.relu(_bn_affine(p, pre + "bn2", y2, True) + scv), f, "b%d.out" % b)
+            else:
+                s1, t1 = _bn_eval_tables(p, pre + "bn1")
+                y1 = q(F.conv2d(cur, qw(p, pre + "conv1.weight"), stride=stride, padding=1))
+                a1 = q(F.relu(y1 * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1)), f, "b%d.a1" % b)
+                if sck in p:
+                    ss, ts = _bn_eval_tables(p, pre + "shortcut.1")
+                    scv = q(F.conv2d(cur, q(p[sck] * ss.view(-1, 1, 1, 1)), stride=stride) + ts.view(1, -1, 1, 1), f,
+                            "b%d.scv" % b)
+                else:
+                    scv = cur
+                s2, t2 = _bn_eval_tables(p, pre + "bn2")
+                v = q(F.conv2d(a1, q(p[pre + "conv2.weight"] * s2.view(-1, 1, 1, 1)), padding=1) + t2.view(1, -1, 1, 1) + scv)
+                cur = q(F.relu(v), f, "b%d.out" % b)
+            b += 1
+    feat = F.avg_pool2d(cur, 4).flatten(1)
+    return F.linear(feat, p["linear.weight"], p["linear.bias"])
+
+
 def unet_forward_emu(p, x, taps=None, force=None):
     """`taps` (dict) receives every stored raw conv output, keyed like the engine's slot buffers;
     `force`: optional {engine slot buffer name: NCHW fp32 tensor} (see :func:`q`)."""

@@ -229,6 +229,75 @@ def test_preact_train_eval(mods, golden):
     check_gx(slot, gr_e, gr_f, "eval1")
 
 
+def test_resnet18_train_eval(mods, golden):
+    """The CelebA classifier (post-activation ResNet18, 64 x 64, 8 classes): train-mode forward with batch
+    statistics + all parameter gradients, then eval-mode forward (folded BatchNorms) + input gradient, as
+    recorded in the golden file; tight against the bf16 emulation (teacher-forced for gradients)."""
+    g = golden("resnet")
+    nets, ops = mods["nets"], mods["ops"]
+    mk = lambda: nets.ResNet18(num_classes=8, input_size=64)
+    m = seeded(mk, int(g["seed"]))
+    names = [k for k, _ in m.named_parameters()]
+    pe = {k: v.clone() for k, v in m.state_dict().items()}
+    for k in names:
+        pe[k].requires_grad_(True)
+    m = m.cuda()
+    eng = m._net_engine()
+    blocks = range(8)
+    keys_train = ["stem", "stem.a"] + ["b%d.%s" % (b, s) for b in blocks for s in ("y1", "a1", "y2", "ys", "out")]
+    keys_eval = ["stem.a"] + ["b%d.%s" % (b, s) for b in blocks for s in ("a1", "scv", "out")]
+
+    def run(tag, train):
+        eng.mark_weights_dirty()
+        eng.refresh()
+        x, t = T(g[tag + "/x"]), T(g[tag + "/t"])
+        xe = x.clone().requires_grad_(True)
+        pe_before = {k: v.clone() for k, v in pe.items() if "running" in k or "num_batches" in k}
+        lg_e = E.resnet_forward_emu(pe, xe, train)
+        loss_e = F.cross_entropy(lg_e, t)
+        gr_e = torch.autograd.grad(loss_e, [xe] + [pe[k] for k in names], allow_unused=True)
+        n, _, hw, _ = x.shape
+        slot = eng.slot(tag, n, hw)
+        ops.image_to_c8(x.cuda(), eng.input(slot))
+        h = eng.head_bufs(slot)
+        h["targets"].copy_(t.cuda())
+        h["loss"].zero_()
+        eng.forward_plan(slot, train).run()
+        assert rel_l2(h["logits"], lg_e.detach()) < 2e-2, tag                     # vs emulation
+        assert abs(float(h["loss"]) - float(loss_e.detach())) < 5e-3, tag
+        assert rel_l2(h["logits"], T(g[tag + "/logits"])) < 3e-2, tag             # vs fp32
+        assert abs(float(h["loss"]) - float(g[tag + "/loss"])) < 1e-2, tag
+        keys = [k for k in (keys_train if train else keys_eval) if k in slot.bufs]
+        xf = x.clone().requires_grad_(True)
+        pf = dict(pe)
+        pf.update({k: v.clone() for k, v in pe_before.items()})
+        lg_f = E.resnet_forward_emu(pf, xf, train, force=stored(slot, keys))
+        assert rel_l2(h["logits"], lg_f.detach()) < 2e-3, tag
+        gr_f = torch.autograd.grad(F.cross_entropy(lg_f, t), [xf] + [pe[k] for k in names], allow_unused=True)
+        return slot, gr_e, gr_f
+
+    slot, gr_e, gr_f = run("train", True)
+    eng.backward_train_plan(slot).run()
+    torch.cuda.synchronize()
+    ours = flat_grads(eng.fp, names)
+    e_tf = rel_l2(ours, torch.cat([a.reshape(-1) for a in gr_f[1:]]))
+    assert e_tf < 4e-2, e_tf                                                      # vs teacher-forced
+    e = sampled_err(g, "train/gp", [(k, eng.fp.logical(eng.fp.grad, k).cpu()) for k in names])
+    emu = sampled_err(g, "train/gp", zip(names, gr_e[1:]))
+    assert e < 0.5 and e < 1.6 * emu, (e, emu)                                    # vs fp32
+    for k, v in m.state_dict().items():
+        if "running" in k:
+            assert rel_l2(v, T(g["train/buf/" + k])) < 5e-3, k
+        if "num_batches" in k:
+            assert int(v) == int(g["train/buf/" + k])
+    slot, gr_e, gr_f = run("eval1", False)
+    eng.backward_eval_plan(slot, 1.0).run()
+    gx = slot.bufs["g.img"][..., :3].float().permute(0, 3, 1, 2)
+    assert rel_l2(gx, gr_f[0]) < 6e-2                                             # vs teacher-forced
+    e, emu = rel_l2(gx, T(g["eval1/gx"])), rel_l2(gr_e[0], T(g["eval1/gx"]))
+    assert e < 0.5 and e < 1.6 * emu + 1e-3, (e, emu)                             # vs fp32
+
+
 def test_frequency_model_vs_golden(mods, golden):
     g = golden("freq")
     nets, ops = mods["nets"], mods["ops"]
