@@ -39,6 +39,25 @@ def _load_cifar10(root: str, train: bool) -> Tuple[np.ndarray, np.ndarray]:
         "downloaded here -- pass --synthetic for CIFAR-10-shaped random data" % root)
 
 
+def _load_celeba(root: str, train: bool, hw: int) -> Tuple[np.ndarray, np.ndarray]:
+    """CelebA as the reference uses it (utils/dataloader.py:63-80: images resized to 64 x 64, label =
+    (attr[18] << 2) + (attr[31] << 1) + attr[21] over torchvision's 40 attribute columns, 8 classes), from a
+    pre-decoded cache `celeba_{train,test}_64.npz` with uint8 `images` [N,64,64,3] (or [N,3,64,64]) and `attr`
+    [N,40] (0/1).  JPEG decoding is outside this package (no image library is assumed); the cache is what
+    a one-off conversion of torchvision.datasets.CelebA(split=train / test, target_type="attr") writes."""
+    path = os.path.join(root, "celeba_%s_%d.npz" % ("train" if train else "test", hw))
+    if not os.path.exists(path):
+        raise FileNotFoundError("CelebA cache %r not found (uint8 images [N,%d,%d,3] + attr [N,40]); nothing is "
+                                "downloaded.  --synthetic runs the same shapes on generated data." % (path, hw, hw))
+    z = np.load(path)
+    attr = z["attr"].astype(np.int64)
+    labels = (attr[:, 18] << 2) + (attr[:, 31] << 1) + attr[:, 21]
+    img = z["images"]
+    if img.shape[-1] == 3:   # NHWC -> the loader's NCHW
+        img = img.transpose(0, 3, 1, 2)
+    return np.ascontiguousarray(img), labels.astype(np.int64)
+
+
 def synthetic_cifar10(n: int, seed: int, hw: int = 32, classes: int = 10) -> Tuple[np.ndarray, np.ndarray]:
     g = np.random.default_rng(seed)
     return g.integers(0, 256, (n, 3, hw, hw), dtype=np.uint8), g.integers(0, classes, n).astype(np.int64)
@@ -96,11 +115,13 @@ def get_dataloader(opt, train: bool = True, pretensor_transform: bool = False, b
     """Same call shape as the reference's ``get_dataloader`` (utils/dataloader.py:98,
     utils/dataloader_cleanbd.py:161 with ``poisoned=True``)."""
     bs = opt.bs if bs is None else bs
-    if opt.dataset != "cifar10":
-        raise Exception("dataset %r: only cifar10 is wired to the HIP path this round (SURVEY section 8(f))" % opt.dataset)
+    if opt.dataset not in ("cifar10", "celeba"):
+        raise Exception("dataset %r is a later SURVEY section-8(f) row (cifar10 and celeba are wired)" % opt.dataset)
     if getattr(opt, "synthetic", False):
         n = getattr(opt, "synthetic_size", 0) or (CIFAR_TRAIN if train else CIFAR_TEST)
         x, y = synthetic_cifar10(n, 1234 if train else 4321, opt.input_height, opt.num_classes)
+    elif opt.dataset == "celeba":
+        x, y = _load_celeba(opt.data_root, train, opt.input_height)
     else:
         x, y = _load_cifar10(opt.data_root, train)
     if getattr(opt, "debug", False):                         # utils/dataloader.py:118-119

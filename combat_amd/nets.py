@@ -175,3 +175,27 @@ class FrequencyModel(_HipModule):
             setattr(self, "bn%d" % i, nn.BatchNorm2d(w))
             cin = w
         self.linear6 = nn.Linear(2048 * INPUT_SIZE_TO_SCALER[input_size], num_classes)
+
+
+def configure_dataset(opt) -> None:
+    """Input dimensions / class count per dataset, as every entry script's main() sets them
+    (train_generator.py:470-486).  imagenet10 (224 x 224, WaNet) is a later SURVEY section-8(f) row."""
+    if opt.dataset == "cifar10":
+        opt.input_height, opt.input_width, opt.input_channel = 32, 32, 3
+    elif opt.dataset == "celeba":
+        opt.input_height, opt.input_width, opt.input_channel = 64, 64, 3
+        opt.num_classes = 8
+    else:
+        raise Exception("Invalid Dataset")
+
+
+def default_classifier(opt):
+    """The `--model default` classifier of a dataset (train_generator.py:90-96): PreActResNet18 for CIFAR-10,
+    ResNet18(num_classes) at 64 x 64 for CelebA."""
+    if getattr(opt, "model", "default") != "default":
+        raise Exception("only the default classifier of each dataset runs on the HIP path")
+    if opt.dataset == "cifar10":
+        return PreActResNet18()
+    if opt.dataset == "celeba":
+        return ResNet18(num_classes=opt.num_classes)
+    raise Exception("dataset %r is a later SURVEY section-8 row; the HIP path covers cifar10 and celeba" % opt.dataset)

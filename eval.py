@@ -10,14 +10,12 @@ import config
 from combat_amd import api
 from combat_amd.data import get_dataloader
 from combat_amd.log import SummaryWriter, progress_bar
-from combat_amd.nets import PreActResNet18, UnetGenerator
+from combat_amd.nets import UnetGenerator, configure_dataset, default_classifier
 from combat_amd.step import create_targets_bd
 
 
 def get_model(opt):
-    if opt.dataset != "cifar10" or opt.model != "default":
-        raise Exception("only cifar10 / PreActResNet18 run on the HIP path this round")
-    return PreActResNet18().to(opt.device), UnetGenerator(opt).to(opt.device)
+    return default_classifier(opt).to(opt.device), UnetGenerator(opt).to(opt.device)
 
 
 def eval(netC, netG, test_dl, tf_writer, opt):
@@ -45,9 +43,7 @@ def eval(netC, netG, test_dl, tf_writer, opt):
 
 def main():
     opt = config.get_arguments().parse_args()
-    if opt.dataset != "cifar10":
-        raise Exception("Invalid Dataset")
-    opt.input_height, opt.input_width, opt.input_channel = 32, 32, 3
+    configure_dataset(opt)
     test_dl = get_dataloader(opt, False, shuffle=False)
     netC, netG = get_model(opt)
     mode = opt.saving_prefix

@@ -442,6 +442,58 @@ def test_alternated_step_vs_oracle(mods, golden, with_aug):
         assert rel_l2(netg.state_dict()[k].detach().cpu(), exp) < 1e-6, k
 
 
+def test_alternated_step_celeba_shape_resnet18(mods):
+    """BASELINE config 4's shape (CelebA: 3 x 64 x 64, 8 classes, ResNet18 surrogate and clean model, UNet at
+    64 x 64): one alternated step against the CPU oracle driven with the bf16-emulating networks.  Phase C
+    from the identical start state (loss, gradient norm, running statistics, parameter update); Phase G's
+    consumed values as bounds (netC differs by then between two bf16 realisations, as in the CIFAR test)."""
+    from oracle import combat_oracle as O
+    step_mod, nets = mods["step"], mods["nets"]
+    mk = lambda: nets.ResNet18(num_classes=8, input_size=64)
+    netc, clean = seeded(mk, 11), seeded(mk, 12)
+    netg = seeded(lambda: nets.UnetGenerator(None), 13)
+    netf = seeded(lambda: nets.FrequencyModel(2, 3, 64), 14).eval()
+    oc, ok, og, of = (_oracle_state(m) for m in (netc, clean, netg, netf))
+    old_c = _oracle_state(netc)
+    b = 8
+    gen = torch.Generator().manual_seed(5)
+    x = ((torch.randint(0, 256, (b, 3, 64, 64), generator=gen, dtype=torch.uint8).float() / 255) - 0.5) / 0.5
+    t = torch.tensor([0, 3, 0, 7, 0, 1, 0, 5])
+    nb, sc, sg = 2, 0.6, 0.9
+    cfg = O.StepConfig(num_classes=8, classifier="resnet18")
+    bufs_c, bufs_g = [None] * len(O.trainable_names(oc)), [None] * len(O.trainable_names(og))
+    ref = O.alternated_step(oc, og, ok, of, bufs_c, bufs_g, x, t, O.StepRandomness(nb, sc, sg, [None] * 5), cfg,
+                            clf_fn=E.resnet_forward_emu, gen_fn=E.unet_forward_emu)
+
+    opt = Opt()
+    opt.num_classes, opt.input_height, opt.input_width, opt.dataset = 8, 64, 64, "celeba"
+    netc, clean, netg, netf = netc.cuda(), clean.cuda().eval(), netg.cuda(), netf.cuda().eval()
+    st = step_mod.AlternatedStep(netc, netg, clean, netf, opt)
+    st.run(x.cuda(), t, step_mod.StepRandomness(nb, sc, sg, [None] * 5))
+    torch.cuda.synchronize()
+    m = st.read_metrics()
+    tol = lambda r: 1e-2 * max(1.0, abs(r))
+    assert abs(m["loss_c_sum"] - ref["loss_c"]) < tol(ref["loss_c"])
+    gn_c = float(st.eC.fp.grad.double().norm())
+    assert abs(gn_c - ref["gnorm_c"]) < 3e-2 * ref["gnorm_c"], (gn_c, ref["gnorm_c"])
+    num = den = 0.0
+    for k in O.trainable_names(oc):
+        d_ref = (oc[k] - old_c[k]).double()
+        d_our = (netc.state_dict()[k].detach().cpu() - old_c[k]).double()
+        num += float(((d_our - d_ref) ** 2).sum())
+        den += float((d_ref ** 2).sum())
+    assert (num / den) ** 0.5 < 0.35, (num / den) ** 0.5
+    for k, v in netc.state_dict().items():
+        if "running_mean" in k or "running_var" in k:
+            assert rel_l2(v, oc[k]) < 1e-2, k
+    assert abs(m["loss_l2_sum"] - ref["loss_l2"]) < 2e-2 * ref["loss_l2"] + 1e-6
+    assert abs(m["loss_ce_sum"] - ref["loss_ce"]) < 0.15 * max(1.0, abs(ref["loss_ce"]))
+    assert abs(m["clean_model_loss_sum"] - ref["clean_model_loss"]) < 0.05 * max(1.0, abs(ref["clean_model_loss"]))
+    gn_g = float(st.eG.fp.grad.double().norm())
+    assert 0.5 * ref["gnorm_g"] < gn_g < 2.0 * ref["gnorm_g"], (gn_g, ref["gnorm_g"])
+    assert all(np.isfinite(v) for v in m.values())
+
+
 def test_alternated_step_runs_with_sampled_randomness_and_empty_poison(mods):
     """Default path: randomness drawn on the host as the reference does; also num_bd == 0 and a
     ragged last batch (B=80 -> here 12) must work (train_generator.py:190-194)."""

@@ -58,3 +58,24 @@ def test_reference_workflow_on_synthetic_data(tmp_path):
     out = run("eval.py", "--saving_prefix", "train_generator", "--load_checkpoint_clean", "train_victim",
               "--load_checkpoint", "train_generator_clean", cwd=cwd)
     assert "Bd ASR:" in out
+
+
+def test_celeba_workflow_on_synthetic_data(tmp_path):
+    """The same three scripts with --dataset celeba (64 x 64, 8 classes, ResNet18 surrogate / clean model,
+    train_generator.py:93-96): checkpoints carry the reference's ResNet18 state-dict layout (122 entries)."""
+    cwd = str(tmp_path)
+    run("train_clean_classifier.py", "--dataset", "celeba", "--saving_prefix", "classifier_clean", "--n_iters", "1", cwd=cwd)
+    clean = os.path.join(cwd, "ckpt", "classifier_clean", "celeba", "celeba_classifier_clean.pth.tar")
+    sd = torch.load(clean, map_location="cpu", weights_only=False)
+    assert len(sd["netC"]) == 122 and sd["netC"]["linear.weight"].shape == (8, 2048)
+    out = run("train_generator.py", "--dataset", "celeba", "--saving_prefix", "train_generator",
+              "--load_checkpoint_clean", "classifier_clean", "--n_iters", "1", cwd=cwd)
+    assert "Clean Acc:" in out and "Saving..." in out
+    gen = os.path.join(cwd, "ckpt", "train_generator_clean", "celeba", "celeba_train_generator_clean.pth.tar")
+    sd = torch.load(gen, map_location="cpu", weights_only=False)
+    assert len(sd["netC"]) == 122 and len(sd["netG"]) == 32
+    assert all(torch.isfinite(v).all() for v in sd["netG"].values())
+    assert all(torch.isfinite(v.float()).all() for v in sd["netC"].values())
+    out = run("eval.py", "--dataset", "celeba", "--saving_prefix", "train_generator", "--load_checkpoint_clean",
+              "classifier_clean", "--load_checkpoint", "train_generator_clean", cwd=cwd)
+    assert "Bd ASR:" in out

@@ -4,7 +4,8 @@ Drop-in for the reference script of the same name: same flags (config.py), same
 ``get_model`` / ``train`` / ``eval`` / ``main`` call signatures, same checkpoint path and keys
 (reference train_generator.py:80-128, 131-318, 321-465, 468-609) -- the per-batch loop body
 (:170-290) runs as ``combat_amd.step.AlternatedStep`` on the HIP kernels.  CIFAR-10 + the default
-PreActResNet18 / UNet / "original" detector only this round; other --model / --dataset values raise.
+default classifier of the dataset (PreActResNet18 for cifar10, ResNet18 for celeba) / UNet / "original" detector;
+other --model / --dataset values raise.
 
 Data parallel: ``python -m torch.distributed.run --nproc-per-node N train_generator.py ...`` gives
 every rank a disjoint shard of each epoch and averages the gradients over RCCL (combat_amd.dist).
@@ -20,7 +21,7 @@ import config
 from combat_amd import api, dist as cdist
 from combat_amd.data import get_dataloader
 from combat_amd.log import SummaryWriter, progress_bar
-from combat_amd.nets import FrequencyModel, PreActResNet18, UnetGenerator
+from combat_amd.nets import FrequencyModel, UnetGenerator, configure_dataset, default_classifier
 from combat_amd.step import AlternatedStep, create_targets_bd  # noqa: F401  (re-exported like the reference)
 
 
@@ -29,12 +30,10 @@ def create_dir(path_dir):
 
 
 def get_model(opt):
-    if opt.dataset != "cifar10":
-        raise Exception("dataset %r is a later SURVEY section-8 row; the HIP path covers cifar10" % opt.dataset)
     if opt.model != "default" or opt.model_clean != "default" or opt.F_model not in ("original", "original_holdout"):
-        raise Exception("only the default PreActResNet18 / UNet / 'original' detector run on the HIP path")
-    netC = PreActResNet18().to(opt.device)
-    clean_model = PreActResNet18().to(opt.device)
+        raise Exception("only the default classifier / UNet / 'original' detector run on the HIP path")
+    netC = default_classifier(opt).to(opt.device)
+    clean_model = default_classifier(opt).to(opt.device)
     netG = UnetGenerator(opt).to(opt.device)
     netF = FrequencyModel(num_classes=2, n_input=opt.input_channel, input_size=opt.input_height).to(opt.device)
     optimizerC = torch.optim.SGD(netC.parameters(), opt.lr_C, momentum=0.9, weight_decay=5e-4, nesterov=True)
@@ -173,10 +172,7 @@ def detector_checkpoint_path(opt):
 
 def main():
     opt = config.get_arguments().parse_args()
-    if opt.dataset == "cifar10":
-        opt.input_height, opt.input_width, opt.input_channel = 32, 32, 3
-    else:
-        raise Exception("Invalid Dataset")
+    configure_dataset(opt)
     rank, local_rank, world = cdist.init()
     if opt.device == "cuda":
         opt.device = "cuda:%d" % local_rank

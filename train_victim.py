@@ -9,14 +9,12 @@ import config
 from combat_amd import api, dist as cdist
 from combat_amd.data import get_dataloader
 from combat_amd.log import SummaryWriter, progress_bar
-from combat_amd.nets import PreActResNet18, UnetGenerator
+from combat_amd.nets import UnetGenerator, configure_dataset, default_classifier
 from combat_amd.step import ClassifierStep, create_targets_bd
 
 
 def get_model(opt):
-    if opt.dataset != "cifar10" or opt.model != "default":
-        raise Exception("only cifar10 / PreActResNet18 run on the HIP path this round")
-    netC = PreActResNet18().to(opt.device)
+    netC = default_classifier(opt).to(opt.device)
     netG = UnetGenerator(opt).to(opt.device)
     optimizerC = torch.optim.SGD(netC.parameters(), opt.lr_C, momentum=0.9, weight_decay=5e-4, nesterov=True)
     schedulerC = torch.optim.lr_scheduler.MultiStepLR(optimizerC, opt.schedulerC_milestones, opt.schedulerC_lambda)
@@ -75,9 +73,7 @@ def eval(netC, optimizerC, schedulerC, netG, test_dl, best_clean_acc, best_bd_ac
 
 def main():
     opt = config.get_arguments().parse_args()
-    if opt.dataset != "cifar10":
-        raise Exception("Invalid Dataset")
-    opt.input_height, opt.input_width, opt.input_channel = 32, 32, 3
+    configure_dataset(opt)
     rank, local_rank, world = cdist.init()
     if opt.device == "cuda":
         opt.device = "cuda:%d" % local_rank
