@@ -53,28 +53,29 @@ class Opt:
     post_transform_option, random_crop, random_rotation = "use", 5, 10
 
 
-def synth_batches(n_batches, bs, rank, device):
+def synth_batches(n_batches, bs, rank, device, hw=32, classes=10):
     """uint8 pixels -> ToTensor + Normalize(0.5, 0.5); labels uniform."""
     g = torch.Generator().manual_seed(1234 + rank)
     out = []
     for _ in range(n_batches):
-        u8 = torch.randint(0, 256, (bs, 3, 32, 32), generator=g, dtype=torch.uint8)
+        u8 = torch.randint(0, 256, (bs, 3, hw, hw), generator=g, dtype=torch.uint8)
         x = ((u8.float() / 255) - 0.5) / 0.5
-        t = torch.randint(0, 10, (bs,), generator=g)
+        t = torch.randint(0, classes, (bs,), generator=g)
         out.append((x.to(device), t))
     return out
 
 
-def build_nets(device):
+def build_nets(device, dataset="cifar10"):
     from combat_amd import nets
+    clf = nets.PreActResNet18 if dataset == "cifar10" else (lambda: nets.ResNet18(num_classes=8, input_size=64))
     torch.manual_seed(0)
-    netc = nets.PreActResNet18()
+    netc = clf()
     torch.manual_seed(1)
-    clean = nets.PreActResNet18().eval()
+    clean = clf().eval()
     torch.manual_seed(2)
     netg = nets.UnetGenerator(None)
     torch.manual_seed(3)
-    netf = nets.FrequencyModel(2, 3, 32).eval()   # shipped detector weights do not travel: default init
+    netf = nets.FrequencyModel(2, 3, 32 if dataset == "cifar10" else 64).eval()   # shipped detector weights do not travel: default init
     return netc.to(device), netg.to(device), clean.to(device), netf.to(device)
 
 
@@ -201,6 +202,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dataset", default="cifar10", choices=("cifar10", "celeba"),
+                    help="cifar10 = BASELINE configs[1] (the metric's configuration); celeba = configs[3]'s shape "
+                         "(64 x 64, 8 classes, ResNet18), informational")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -227,17 +231,19 @@ def main():
 
     from combat_amd import step as step_mod
     opt = Opt()
+    if args.dataset == "celeba":
+        opt.dataset, opt.input_height, opt.input_width, opt.num_classes = "celeba", 64, 64, 8
     np.random.seed(rank)
     import random
     random.seed(rank)
     torch.manual_seed(100 + rank)
-    netc, netg, clean, netf = build_nets(device)
+    netc, netg, clean, netf = build_nets(device, args.dataset)
     if world > 1:   # identical replicas: rank 0's parameters everywhere
         for m in (netc, netg, clean, netf):
             for p in list(m.parameters()) + list(m.buffers()):
                 torch.distributed.broadcast(p.data, 0)
     st = step_mod.AlternatedStep(netc, netg, clean, netf, opt, process_group=pg)
-    batches = synth_batches(8, opt.bs, rank, device)
+    batches = synth_batches(8, opt.bs, rank, device, opt.input_height, opt.num_classes)
 
     def sync():
         if world > 1:
@@ -301,7 +307,12 @@ def main():
                        "gflop_per_image_algorithmic": 11.67, "losses_finite": finite},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.dataset != "cifar10":
+            out["config"]["workload"] = ("train_generator.py --dataset celeba: alternated ResNet18 surrogate + UNet generator "
+                                         "step at 64 x 64, 8 classes, bs=128 per GPU (informational; the metric's "
+                                         "configuration is cifar10)")
+            out["config"].pop("gflop_per_image_algorithmic", None)
+        if world == 1 and not args.no_cpu_baseline and args.dataset == "cifar10":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
