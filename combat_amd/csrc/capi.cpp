@@ -1,7 +1,8 @@
 // Library identity for the combat_hip C ABI (include/combat_hip.h).
 #include "combat_hip.h"
 
-#define COMBAT_ABI_VERSION 2
+// 3: combat_pack_desc.row_scale, fused normalisation entries, combat_relu_mask, tile ids 10-15, conv / wgrad workspaces
+#define COMBAT_ABI_VERSION 3
 
-extern "C" const char *combat_version(void) { return "combat_hip gfx950 abi1"; }
+extern "C" const char *combat_version(void) { return "combat_hip gfx950 abi3"; }
 extern "C" int combat_abi_version(void) { return COMBAT_ABI_VERSION; }
