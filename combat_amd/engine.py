@@ -159,15 +159,8 @@ class NormState:
         mk = lambda s: slot.buf("%s.%s" % (key, s), (groups, c), f32)
         self.groups, self.C = groups, c
         self.mean, self.rstd, self.scale, self.shift = mk("mean"), mk("rstd"), mk("scale"), mk("shift")
-        self.ca = self.cb = self.cc = None
         self.pending = self.bpending = None    # statistics waiting for their fused finalize+apply launch
         self._slot, self._key = slot, key
-
-    def bwd_coeffs(self):
-        if self.ca is None:
-            mk = lambda s: self._slot.buf("%s.%s" % (self._key, s), (self.groups, self.C), f32)
-            self.ca, self.cb, self.cc = mk("ca"), mk("cb"), mk("cc")
-        return self.ca, self.cb, self.cc
 
 
 class FlatParams:
