@@ -275,6 +275,35 @@ def test_conv_forward_plain(ops, n, hw, c, k, r, stride, pad, tile):
     assert rel_l2(nchw(y), ref) < 4e-3
 
 
+@pytest.mark.parametrize("n,hw,c,k,r,stride", [
+    (3, 12, 64, 128, 3, 2), (2, 20, 128, 64, 3, 2), (5, 6, 64, 64, 3, 2), (3, 12, 64, 128, 1, 2), (2, 10, 64, 64, 3, 1),
+    (7, 4, 256, 512, 3, 2), (4, 32, 64, 128, 3, 2), (9, 2, 512, 512, 3, 1)])
+def test_gather_dma_odd_shapes_forward_and_dgrad(ops, n, hw, c, k, r, stride):
+    """The gather kernel's per-lane row offsets and tap-validity masks are computed once per workgroup (shift
+    decode for power-of-two maps, divisions otherwise; parity-class pixel order for stride-2 input gradients;
+    split reductions for skinny layers): sizes that are not powers of two, ragged last tiles, 1x1 filters."""
+    from combat_amd._lib import lib
+    import ctypes
+    pad = 1 if r == 3 else 0
+    x = torch.randn(n, c, hw, hw, generator=g(301))
+    w, pc = make_conv(ops, k, c, r, stride, pad, 302)
+    p, q = pc.out_hw(hw, hw)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    y = torch.empty(n, p, q, k, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(x), y, pc, 0, workspace=ws)
+    tile = lib.combat_conv_pick_tile(ctypes.byref(a))
+    assert tile in (10, 11, 12, 13), tile
+    ops.conv_launch(a)
+    assert rel_l2(nchw(y), F.conv2d(rb(x), rb(w), stride=stride, padding=pad)) < 4e-3
+    dy = torch.randn(n, k, p, q, generator=g(303))
+    dx = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(dy), dx, pc, 1, workspace=ws)
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) in (10, 11, 12, 13)
+    ops.conv_launch(a)
+    ref = torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), stride=stride, padding=pad)
+    assert rel_l2(nchw(dx), ref) < 4e-3
+
+
 def test_conv_forward_bn_relu_prologue_residual_stats(ops):
     """PreAct conv2: relu(bn(x)) prologue, `out += shortcut` epilogue, next-BN statistics."""
     n, hw, c = 4, 16, 128
