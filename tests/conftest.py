@@ -11,6 +11,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is a build artefact (not in history): a fresh checkout builds it once (hipcc
+    # cross-compiles gfx950 without a GPU); the product path itself never builds or falls back on its own
+    lib = os.path.join(ROOT, "combat_amd", "libcombat_hip.so")
+    if not os.path.exists(lib) and not os.environ.get("COMBAT_HIP_LIB"):
+        from combat_amd import build
+        build.build()
 
 
 def pytest_collection_modifyitems(config, items):
