@@ -20,6 +20,7 @@ namespace {
 struct WgradParams {
     combat_wgrad_args a;
     int M, PQ, ntaps, tiles_k, tiles_c, split, pix_per_split;
+    float *ws;   // C = 8 kernel: per-workgroup partial gradients (plain stores + a reduction launch instead of atomics)
 };
 
 template <int BMC, int BNC>
@@ -233,6 +234,217 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
+// ------------------------------------------------------------------ C = 8 inputs, all nine taps per workgroup
+// The generic kernel gives every filter tap its own workgroups, so a layer re-reads dy nine times and a
+// 64-pixel step feeds two MFMAs per wave: for the 8-channel inputs (classifier stems, the generator's first
+// convolution; they are the LAST weight gradients of their backward passes, fully exposed) that was 46-59 us.
+// Here the "column" operand of a step is the pixel's im2col row [9 taps x 8 channels (+ 8 zeros)] = 80 columns,
+// gathered by nine 16-byte loads per pixel from the (cache-resident, 2 MB) input, so dy is staged once and a
+// step feeds ten MFMAs per wave.  64 dy channels per workgroup (four waves x 16), pixel ranges over the grid,
+// fp32 atomics into dW as the generic kernel.
+__global__ __launch_bounds__(256) void conv_wgrad_c8_kernel(const WgradParams p) {
+    constexpr int BMC = 64, NCOL = 80, SK = (BMC + 16) * 2, SC = (NCOL + 16) * 2, BUF = 64 * (SK + SC);
+    constexpr int CHK = BMC / 8, CHC = NCOL / 8, ITK = (64 * CHK + 255) / 256, ITC = (64 * CHC + 255) / 256;
+    constexpr int FC = NCOL / 16, EPS = NCOL + 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const combat_wgrad_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int bid = blockIdx.x;
+    const int tile_k = bid % p.tiles_k;
+    const int sp = bid / p.tiles_k;
+    const int k0 = tile_k * BMC;
+    const int m_begin = sp * p.pix_per_split;
+    int m_end = m_begin + p.pix_per_split;
+    if (m_end > p.M) m_end = p.M;
+    const int nkt = (m_end - m_begin + 63) / 64;
+    if (nkt <= 0) return;
+    const __bf16 *__restrict__ src = reinterpret_cast<const __bf16 *>(a.src);
+    const __bf16 *__restrict__ dy = reinterpret_cast<const __bf16 *>(a.dy);
+    const int K = a.K, H = a.H, W = a.W;
+    u32x4_t rk[ITK];
+    uint4 rc[ITC];
+    auto load_tile = [&](int kt) {
+        const int mt = m_begin + kt * 64;
+#pragma unroll
+        for (int i = 0; i < ITK; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CHK, ch = idx % CHK;
+            const int m = mt + row;
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (idx < 64 * CHK && m < m_end) v = *reinterpret_cast<const u32x4_t *>(dy + (size_t)m * K + k0 + ch * 8);
+            rk[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < ITC; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CHC, tap = idx % CHC;      // chunk = filter tap (9: zero padding)
+            const int m = mt + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (idx < 64 * CHC && m < m_end && tap < 9) {
+                const int img = m / p.PQ, rem = m - img * p.PQ;
+                const int oy = rem / a.Q, ox = rem - oy * a.Q;
+                const int r = (tap * 11) >> 5, s = tap - r * 3;
+                const int iy = oy * a.stride - a.pad + r, ix = ox * a.stride - a.pad + s;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+                    v = *reinterpret_cast<const uint4 *>(src + ((size_t)(img * H + iy) * W + ix) * 8);
+            }
+            rc[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char *kl = smem + buf * BUF;
+        unsigned char *cl = kl + 64 * SK;
+#pragma unroll
+        for (int i = 0; i < ITK; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 64 * CHK) *reinterpret_cast<u32x4_t *>(kl + (idx / CHK) * SK + (idx % CHK) * 16) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < ITC; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 64 * CHC) *reinterpret_cast<uint4 *>(cl + (idx / CHC) * SC + (idx % CHC) * 16) = rc[i];
+        }
+    };
+    f32x4_t acc[FC];
+#pragma unroll
+    for (int j = 0; j < FC; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+        const unsigned char *kl = smem + buf * BUF;
+        const unsigned char *cl = kl + 64 * SK;
+        const int q = (lane & 15) >> 2, pp = lane & 3, fq = lane >> 4;
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        bf16x8_t fk[2], fc[2][FC];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int prow = ks * 32 + fq * 8 + q;
+            {
+                const unsigned char *b = kl + prow * SK + (wid * 16 + pp * 4) * 2;
+                const s16x4_t lo = lds_tr16(b), hi = lds_tr16(b + 4 * SK);
+                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fk[ks] = __builtin_bit_cast(bf16x8_t, v);
+            }
+#pragma unroll
+            for (int j = 0; j < FC; ++j) {
+                const unsigned char *b = cl + prow * SC + (j * 16 + pp * 4) * 2;
+                const s16x4_t lo = lds_tr16(b), hi = lds_tr16(b + 4 * SC);
+                const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                fc[ks][j] = __builtin_bit_cast(bf16x8_t, v);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < FC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[ks], fc[ks][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile(kt + 1);
+        compute(kt & 1);
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+    float *ep = reinterpret_cast<float *>(smem);
+    {
+        const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < FC; ++j) {
+            const int col = j * 16 + fr, row = wid * 16 + fq * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ep[(row + e) * EPS + col] = acc[j][e];
+        }
+    }
+    __syncthreads();
+    const int creal = a.c_real;
+    if (p.ws) {
+        // dW of these layers is a few thousand floats: hundreds of workgroups adding into it atomically
+        // serialise on the same addresses (that, not the arithmetic, was the generic kernel's 58 us).
+        // Each workgroup stores its folded partial [64][9][creal]; conv_wgrad_c8_reduce_kernel sums them.
+        float *slab = p.ws + (size_t)blockIdx.x * (BMC * 9 * creal);
+        for (int idx = tid; idx < BMC * 9 * creal; idx += 256) {
+            const int row = idx / (9 * creal), rem = idx - row * 9 * creal;
+            const int tap = rem / creal, c = rem - tap * creal;
+            float v = ep[row * EPS + tap * 8 + c];
+            if (creal < 8 && c + creal < 8) v += ep[row * EPS + tap * 8 + c + creal];   // hi/lo image channels fold
+            slab[idx] = v;
+        }
+        return;
+    }
+    for (int idx = tid; idx < BMC * 72; idx += 256) {
+        const int row = idx / 72, col = idx - row * 72;
+        const int n = k0 + row, tap = col >> 3;
+        int c = col & 7;
+        if (n >= a.k_real) continue;
+        if (creal < 8) {  // hi/lo image channels fold onto the real ones
+            if (c >= 2 * creal) continue;
+            if (c >= creal) c -= creal;
+        }
+        atomicAdd(a.dw + ((size_t)n * 9 + tap) * creal + c, ep[row * EPS + col]);
+    }
+}
+
+// dw[(k0 + row)][tap][c] += sum over pixel ranges of the slabs [range][k tile][64][9][creal]
+__global__ __launch_bounds__(256) void conv_wgrad_c8_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw,
+                                                                   int tiles_k, int split, int per_tile, int k_real,
+                                                                   int row_elems) {
+    // blockIdx.z = one of gridDim.z interleaved groups of pixel ranges (a thread walking all of them alone is a
+    // chain of `split` dependent round trips); the groups meet in dw with a handful of atomics per element
+    const int e = blockIdx.x * 256 + threadIdx.x, tile_k = blockIdx.y;
+    if (e >= per_tile) return;
+    const int n = tile_k * 64 + e / row_elems;
+    if (n >= k_real) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int G = gridDim.z;
+    int sp = blockIdx.z;
+    for (; sp + 3 * G < split; sp += 4 * G) {
+        s0 += ws[((size_t)sp * tiles_k + tile_k) * per_tile + e];
+        s1 += ws[((size_t)(sp + G) * tiles_k + tile_k) * per_tile + e];
+        s2 += ws[((size_t)(sp + 2 * G) * tiles_k + tile_k) * per_tile + e];
+        s3 += ws[((size_t)(sp + 3 * G) * tiles_k + tile_k) * per_tile + e];
+    }
+    for (; sp < split; sp += G) s0 += ws[((size_t)sp * tiles_k + tile_k) * per_tile + e];
+    atomicAdd(dw + (size_t)tile_k * per_tile + e, (s0 + s1) + (s2 + s3));
+}
+
+int launch_c8(WgradParams p, hipStream_t st) {
+    constexpr int SMEM = 2 * 64 * ((64 + 16) * 2 + (80 + 16) * 2);   // two stages; the fp32 epilogue image (64 x 84 x 4) fits
+    static_assert(SMEM >= 64 * 84 * 4, "epilogue image");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_c8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_set = true;
+    }
+    p.tiles_k = p.a.K / 64;
+    p.tiles_c = 1;
+    int split = p.a.split;
+    const int ktiles = (p.M + 63) / 64;
+    if (split <= 0) {
+        split = (256 + p.tiles_k - 1) / p.tiles_k;
+        const int max_split = (ktiles + 3) / 4;
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+    }
+    if (split > ktiles) split = ktiles;
+    p.pix_per_split = ((ktiles + split - 1) / split) * 64;
+    p.split = (p.M + p.pix_per_split - 1) / p.pix_per_split;
+    const int per_tile = 64 * 9 * p.a.c_real;
+    const long need = (long)p.tiles_k * p.split * per_tile * 4;
+    p.ws = (p.split > 1 && p.a.workspace && p.a.workspace_bytes >= need) ? reinterpret_cast<float *>(p.a.workspace) : nullptr;
+    hipLaunchKernelGGL(conv_wgrad_c8_kernel, dim3((unsigned)(p.tiles_k * p.split)), dim3(256), SMEM, st, p);
+    CB_LAUNCH_CHECK();
+    if (p.ws) {
+        hipLaunchKernelGGL(conv_wgrad_c8_reduce_kernel, dim3((per_tile + 255) / 256, p.tiles_k, p.split >= 32 ? 16 : 1), dim3(256), 0, st, p.ws,
+                           p.a.dw, p.tiles_k, p.split, per_tile, p.a.k_real, 9 * p.a.c_real);
+        CB_LAUNCH_CHECK();
+    }
+    return COMBAT_OK;
+}
+
 template <int BMC, int BNC>
 int launch(WgradParams p, hipStream_t st) {
     using T = WCfg<BMC, BNC>;
@@ -282,6 +494,7 @@ extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
     if ((a->pro_scale == nullptr) != (a->pro_shift == nullptr)) return COMBAT_EINVAL;
     WgradParams p;
     p.a = *a;
+    p.ws = nullptr;
     p.PQ = a->P * a->Q;
     const long M = (long)a->N * p.PQ;
     if (M > 0x7fffffffL / 8) return COMBAT_EINVAL;
@@ -294,6 +507,7 @@ extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
         if (rc <= 0) return rc;
     }
     if (a->split < 0) p.a.split = 0;
+    if (a->split >= 0 && a->C == 8 && a->R == 3 && (a->K & 63) == 0 && !a->pro_scale && !a->pro_act) return launch_c8(p, st);
     if (a->C <= 16) return launch<64, 16>(p, st);
     if (a->K <= 16) return launch<16, 64>(p, st);
     if (a->C % 128 == 0 && a->K % 128 == 0) return launch<128, 128>(p, st);

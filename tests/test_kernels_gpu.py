@@ -370,7 +370,8 @@ def test_conv_forward_hilo_stem(ops):
 
 @pytest.mark.parametrize("n,hw,c,k,r,stride,pad", [
     (4, 16, 64, 64, 3, 1, 1), (2, 32, 64, 128, 3, 2, 1), (2, 32, 64, 128, 1, 2, 0), (8, 4, 512, 512, 3, 1, 1),
-    (3, 6, 128, 256, 3, 2, 1), (4, 32, 3, 64, 3, 1, 1), (4, 16, 64, 3, 3, 1, 1)])
+    (3, 6, 128, 256, 3, 2, 1), (4, 32, 3, 64, 3, 1, 1), (4, 16, 64, 3, 3, 1, 1),
+    (3, 10, 3, 64, 3, 2, 1), (5, 16, 3, 128, 3, 2, 1), (2, 12, 3, 64, 3, 1, 1)])   # 8-channel inputs: all-taps kernel
 def test_conv_dgrad_and_wgrad(ops, n, hw, c, k, r, stride, pad):
     c_pad = 8 if c == 3 else c
     x = torch.randn(n, c, hw, hw, generator=g(20))
