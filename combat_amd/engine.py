@@ -238,7 +238,9 @@ def rec_conv(plan: Plan, what: str, src, dst, pc: PackedConv, mode: int, **kw):
     return a
 
 
-def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[Affine] = None):
+def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[Affine] = None, aux: bool = True):
+    """aux=False: the LAST weight gradient of a backward pass stays on the plan's own stream, beside the
+    second-to-last one on the auxiliary stream (nothing is left to hide it behind)."""
     a = ops.WgradArgs()
     a.N, a.H, a.W, a.C = src.shape
     _, a.P, a.Q, a.K = dy.shape
@@ -252,7 +254,7 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
     ws = _wgrad_workspace(src.device)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     plan.hold(a, src, dy, dw, pro, ws)
-    plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a), aux=True)
+    plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a), aux=aux)
 
 
 _WGRAD_WS: Dict = {}
@@ -704,7 +706,7 @@ class PreActEngine(NetEngine):
             d_out = dxin
             if b in (6, 4, 2):   # layer4 / layer3 / layer2 complete: their gradient range can travel
                 P.mark(fp.offsets[pre + "bn1.weight"][0])
-        rec_wgrad(P, "stem.wgrad", self.input(slot), d_out, self.stem, fp.grad_phys("conv1.weight"))
+        rec_wgrad(P, "stem.wgrad", self.input(slot), d_out, self.stem, fp.grad_phys("conv1.weight"), aux=False)
         P.mark(0)
         slot.plans[key] = P
         return P
@@ -931,7 +933,7 @@ class ResNetEngine(PreActEngine):
                                  add_pre=other)
                 dy0 = G("stem.dy", y0)
                 self._bwd_apply(P, slot, "g." + self.bn0.prefix, dz0, y0, dy0, st0)
-                rec_wgrad(P, "stem.wgrad", self.input(slot), dy0, self.stem, fp.grad_phys("conv1.weight"))
+                rec_wgrad(P, "stem.wgrad", self.input(slot), dy0, self.stem, fp.grad_phys("conv1.weight"), aux=False)
         P.mark(0)
         slot.plans[key] = P
         return P
@@ -1141,7 +1143,7 @@ class UnetEngine(NetEngine):
         rec_conv(P, "conv0_1.dgrad", d, d00, pc["conv0_1"], 1, mask_x=t00, mask=Affine(None, None, 0, True, self.LR))
         P.add("db.conv0_0", lib.combat_colsum, d00.data_ptr(), d00.numel() // d00.shape[-1], d00.shape[-1],
               d00.shape[-1], fp.grad_phys("conv0_0.bias").data_ptr())
-        rec_wgrad(P, "conv0_0.wgrad", self.input(slot), d00, pc["conv0_0"], fp.grad_phys("conv0_0.weight"))
+        rec_wgrad(P, "conv0_0.wgrad", self.input(slot), d00, pc["conv0_0"], fp.grad_phys("conv0_0.weight"), aux=False)
         P.mark(0)
         slot.plans["bwd"] = P
         return P
