@@ -464,7 +464,8 @@ int launch(WgradParams p, hipStream_t st) {
         const int base = p.tiles_k * p.tiles_c * p.ntaps;
         // ~one workgroup per CU: the launch runs beside the input-gradient chain (auxiliary stream), and fewer,
         // longer workgroups mean fewer fp32 atomics (whole step: 256 -> 5.02 ms, 1024 -> 5.06, 128 -> 5.08, 64 -> 5.41)
-        split = (256 + base - 1) / base;
+        // (K <= 16 rows -- the generator's 3-channel output: a block is a sliver of work, 2304 of them halve the time)
+        split = ((BMC == 16 ? 2304 : 256) + base - 1) / base;
         const int max_split = (ktiles + 3) / 4;  // at least 4 reduction steps per block
         if (split > max_split) split = max_split;
         if (split < 1) split = 1;
