@@ -220,6 +220,23 @@ class FlatParams:
             return g.view(k, r, s, c).permute(0, 3, 1, 2)
         return g.view(shape)
 
+    zero_ev = None   # set while an early zeroing of `grad` is in flight on the auxiliary stream
+
+    def zero_grad_behind(self) -> None:
+        """Call right after the optimiser consumed the gradients: the buffer is zeroed on the auxiliary stream
+        now, instead of by the first call of the next backward plan on the critical queue (9 us + a launch
+        gap per network and step).  The plan's `zero_grad` entry then only waits for the event."""
+        if Plan.serial:
+            return
+        main = torch.cuda.current_stream()
+        aux = _aux_stream(main)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        aux.wait_event(ev)
+        ops.check(lib.combat_memset_zero(self.grad.data_ptr(), self.total * 4, aux.cuda_stream), "zero_grad")
+        self.zero_ev = torch.cuda.Event()
+        self.zero_ev.record(aux)
+
     def sgd_step(self, lr: float, momentum: float = 0.9, weight_decay: float = 5e-4, grad_scale: float = 1.0):
         """torch.optim.SGD(nesterov=True) on the whole buffer: the momentum buffer starts at zero,
         so `buf = mu*buf + g` equals torch's first-step `buf = g`."""
@@ -229,6 +246,17 @@ class FlatParams:
 # --------------------------------------------------------------------------------------------
 # recording helpers
 # --------------------------------------------------------------------------------------------
+
+
+def _zero_grad_call(fp, st):
+    """First call of a backward plan: zero the flat gradient buffer -- or, if FlatParams.zero_grad_behind()
+    already did that behind the previous optimiser step, just order this stream after it."""
+    ev = fp.zero_ev
+    if ev is not None:
+        fp.zero_ev = None
+        torch.cuda.current_stream().wait_event(ev)
+        return 0
+    return lib.combat_memset_zero(fp.grad.data_ptr(), fp.total * 4, st)
 
 
 def rec_conv(plan: Plan, what: str, src, dst, pc: PackedConv, mode: int, **kw):
@@ -670,7 +698,7 @@ class PreActEngine(NetEngine):
         P = Plan("preact." + key)
         fp, n = self.fp, slot.N
         h = self.head_bufs(slot)
-        P.add("zero_grad", lib.combat_memset_zero, fp.grad.data_ptr(), fp.total * 4)
+        P.add("zero_grad", _zero_grad_call, fp)
         feat = slot.bufs["b%d.out" % (len(self.blocks) - 1)]
         d_out = slot.buf("g.feat", feat.shape)
         P.add("head_bwd", lib.combat_head_bwd, h["pooled"].data_ptr(), n, slot.feat_hw, feat.shape[-1],
@@ -886,7 +914,7 @@ class ResNetEngine(PreActEngine):
         P = Plan("resnet." + key)
         fp = self.fp
         G = lambda name, like: slot.buf("g." + name, like.shape)
-        P.add("zero_grad", lib.combat_memset_zero, fp.grad.data_ptr(), fp.total * 4)
+        P.add("zero_grad", _zero_grad_call, fp)
         d_out = self._head_grad(P, slot, loss_weight, True)
 
         def bn_bwd(bn, key_, dz, x_pre, name):
@@ -1083,7 +1111,7 @@ class UnetEngine(NetEngine):
         t = lambda name: slot.bufs["t." + name]
         stn = lambda name: slot.norm[name]
         G = lambda name, like: slot.buf("g." + name, like.shape)
-        P.add("zero_grad", lib.combat_memset_zero, fp.grad.data_ptr(), fp.total * 4)
+        P.add("zero_grad", _zero_grad_call, fp)
         gz = slot.buf("g.z", (n, hw, hw, 8))
         P.add("db.upconv0_0", lib.combat_colsum, gz.data_ptr(), n * hw * hw, 8, 3,
               fp.grad_phys("upconv0_0.bias").data_ptr())

@@ -100,6 +100,8 @@ class AlternatedStep:
     """Owns the engines, slots and small device tables of one rank's step."""
 
     serial = False   # True: no second stream (bench.py's instrumented replay times one kernel at a time)
+    keep_grads = False   # True: leave the flat gradient buffers as the step computed them (tests inspect them);
+    #                      default: they are zeroed behind each optimiser step, off the critical queue
     kStage = 4   # pinned staging sets (host steps in flight before it has to wait for the device)
 
     def __init__(self, netC, netG, clean_model, netF, opt, process_group=None):
@@ -325,6 +327,8 @@ class AlternatedStep:
 
         self._backward_allreduce(pl["C_train_b"], eC, prof)
         eC.fp.sgd_step(float(lr_c if lr_c is not None else opt.lr_C), grad_scale=1.0 / self.world)
+        if not self.keep_grads:
+            eC.fp.zero_grad_behind()
         eC.mark_weights_dirty()
         eC.refresh()                       # re-pack bf16 operands, fold the new running stats
 
@@ -362,6 +366,8 @@ class AlternatedStep:
                                          l2_scale, 1, self.sG.buf("g.z", (n, hw, hw, 8)).data_ptr(), st), "trigger bwd")
         self._backward_allreduce(pl["G_b"], eG, prof)
         eG.fp.sgd_step(float(lr_g if lr_g is not None else opt.lr_G), grad_scale=1.0 / self.world)
+        if not self.keep_grads:
+            eG.fp.zero_grad_behind()
         eG.mark_weights_dirty()
         # the next step rewrites the images, the step table and netC's operands under the second stream's readers
         torch.cuda.current_stream().wait_event(ev_met)

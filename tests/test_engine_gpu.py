@@ -381,6 +381,7 @@ def test_alternated_step_vs_oracle(mods, golden, with_aug):
     opt.post_transform_option = "use" if with_aug else "no_use"
     netc, clean, netg, netf = netc.cuda(), clean.cuda().eval(), netg.cuda(), netf.cuda().eval()
     st = step_mod.AlternatedStep(netc, netg, clean, netf, opt)
+    st.keep_grads = True      # the gradient buffers are inspected below
     st.run(x.cuda(), t, step_mod.StepRandomness(nb, sc, sg, augs_k))
     torch.cuda.synchronize()
     m = st.read_metrics()
@@ -469,6 +470,7 @@ def test_alternated_step_celeba_shape_resnet18(mods):
     opt.num_classes, opt.input_height, opt.input_width, opt.dataset = 8, 64, 64, "celeba"
     netc, clean, netg, netf = netc.cuda(), clean.cuda().eval(), netg.cuda(), netf.cuda().eval()
     st = step_mod.AlternatedStep(netc, netg, clean, netf, opt)
+    st.keep_grads = True      # the gradient buffers are inspected below
     st.run(x.cuda(), t, step_mod.StepRandomness(nb, sc, sg, [None] * 5))
     torch.cuda.synchronize()
     m = st.read_metrics()
