@@ -1022,6 +1022,8 @@ class UnetEngine(NetEngine):
             self.pc[name] = self._pc(conv.weight.data, stride, 1, cin_pad, dup=(ci == 0), need_dgrad=(ci != 0))
             self.bias[name] = conv.bias.data if conv.bias is not None else None
         self.out_bias8 = torch.zeros(8, dtype=f32, device=self.device)
+        self.ones = torch.ones(64 * 8, dtype=f32, device=self.device)
+        self.zeros = torch.zeros(64 * 8, dtype=f32, device=self.device)
 
     def _refresh_extra(self):
         b = self.bias["upconv0_0"]
@@ -1047,8 +1049,10 @@ class UnetEngine(NetEngine):
         h1, h2, h3, h4 = hw // 2, hw // 4, hw // 8, hw // 16
         pc, bs = self.pc, self.bias
         t00 = T("conv0_0", h1, nf)
-        rec_conv(P, "conv0_0", x, t00, pc["conv0_0"], 0, bias=bs["conv0_0"])
-        lr_only = Affine(None, None, 0, True, self.LR)
+        # conv0_1 reads LeakyReLU(conv0_0 output), no norm in between: the activation is conv0_0's second output
+        a01 = slot.buf("a.conv0_1", t00.shape)
+        rec_conv(P, "conv0_0", x, t00, pc["conv0_0"], 0, bias=bs["conv0_0"], act_dst=a01,
+                 act=Affine(self.ones, self.zeros, 0, True, self.LR))
 
         def cn(name, src, s, c, pro, defer=False):
             # pro: None (src is used as is), an Affine (activation only), or the NormState of src whose
@@ -1067,7 +1071,7 @@ class UnetEngine(NetEngine):
             return dst, st
 
         # defer=True: the layer's InstanceNorm is finalised by the launch that writes the next conv's input
-        t01, s01 = cn("conv0_1", t00, h1, nf, lr_only, True)
+        t01, s01 = cn("conv0_1", a01, h1, nf, None, True)
         t10, s10 = cn("conv1_0", t01, h2, nf * 2, s01, True)
         t11, s11 = cn("conv1_1", t10, h2, nf * 2, s10, True)
         t20, s20 = cn("conv2_0", t11, h3, nf * 4, s11, True)
