@@ -1118,7 +1118,7 @@ class UnetEngine(NetEngine):
         P.add("zero_grad", _zero_grad_call, fp)
         gz = slot.buf("g.z", (n, hw, hw, 8))
         P.add("db.upconv0_0", lib.combat_colsum, gz.data_ptr(), n * hw * hw, 8, 3,
-              fp.grad_phys("upconv0_0.bias").data_ptr())
+              fp.grad_phys("upconv0_0.bias").data_ptr(), aux=True)
 
         def through_norm(name, dy, pcv, src_name, add_pre=None):
             """dy = gradient w.r.t. raw output of conv `pcv` whose input is LR(IN(t[src_name])).
@@ -1174,7 +1174,7 @@ class UnetEngine(NetEngine):
         d00 = G("conv0_0.dx", t00)
         rec_conv(P, "conv0_1.dgrad", d, d00, pc["conv0_1"], 1, mask_x=t00, mask=Affine(None, None, 0, True, self.LR))
         P.add("db.conv0_0", lib.combat_colsum, d00.data_ptr(), d00.numel() // d00.shape[-1], d00.shape[-1],
-              d00.shape[-1], fp.grad_phys("conv0_0.bias").data_ptr())
+              d00.shape[-1], fp.grad_phys("conv0_0.bias").data_ptr(), aux=True)
         rec_wgrad(P, "conv0_0.wgrad", self.input(slot), d00, pc["conv0_0"], fp.grad_phys("conv0_0.weight"), aux=False)
         P.mark(0)
         slot.plans["bwd"] = P
