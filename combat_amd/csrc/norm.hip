@@ -485,6 +485,150 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const FusedBwdArgs 
     }
 }
 
+// ------------------------------------------------------------------ InstanceNorm finalisation + UNet decoder glue
+// combat_norm_finalize + combat_unet_up_fwd in one launch for the decoder inputs whose InstanceNorm has no
+// activation tensor of its own (the normalised map is only ever consumed through the bilinear upsample):
+//   out = lrelu_0.2( up2x( IN(y) [+ lrelu_0.2(s * ss + ts)] ) ),  IN statistics from the partial rows / from y.
+// Workgroup = (64 channels, a band of output rows, one image); it finalises its image's 64 channels as the
+// fused kernels above do (bands repeat that: <= 32 rows), band 0 publishes mean / rstd / scale / shift.
+struct UpFusedArgs {
+    const __bf16 *y, *s;
+    __bf16 *out;
+    const float *part;
+    int rpg, C, H, W, band;      // band = output rows per workgroup
+    float eps;
+    const float *ss, *ts;
+    float *mean, *rstd, *scale, *shift;
+};
+
+__device__ __forceinline__ void up_taps2(int o, int n, int &i0, int &i1, float &w0, float &w1) {
+    const int i = o >> 1;
+    if (o & 1) {
+        i0 = i;
+        i1 = i + 1 < n ? i + 1 : n - 1;
+        w0 = 0.75f;
+        w1 = 0.25f;
+    } else {
+        i0 = i > 0 ? i - 1 : 0;
+        i1 = i;
+        w0 = 0.25f;
+        w1 = 0.75f;
+    }
+}
+
+__global__ __launch_bounds__(256) void unet_up_fused_kernel(const UpFusedArgs a) {
+    const int tid = threadIdx.x, co = tid & 7, pl = tid >> 3;
+    const int c = blockIdx.x * 64 + co * 8, band = blockIdx.y, g = blockIdx.z;
+    const bool live = c < a.C;
+    const long pxg = (long)a.H * a.W;
+    double s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.0;
+    if (live) {
+        if (a.part) {
+            for (int r = pl; r < a.rpg; r += 32) {
+                const float *p = a.part + (((long)g * a.rpg + r) * 2) * a.C + c;
+                float u[8], v[8];
+                load8f(p, u);
+                load8f(p + a.C, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += (double)u[e];
+                    s2[e] += (double)v[e];
+                }
+            }
+        } else {
+            float f1[8], f2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f1[e] = f2[e] = 0.f;
+            for (long i = pl; i < pxg; i += 32) {
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4 *>(a.y + ((long)g * pxg + i) * a.C + c), v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    f1[e] += v[e];
+                    f2[e] = fmaf(v[e], v[e], f2[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1[e] = (double)f1[e];
+                s2[e] = (double)f2[e];
+            }
+        }
+    }
+    __shared__ double sums[4][8][16];
+    __shared__ float coef[2][64];
+    fused_combine(s1, s2, tid, sums);
+    if (tid < 64) {
+        const int cc = blockIdx.x * 64 + tid;
+        double t1, t2;
+        fused_channel_sums(sums, tid, t1, t2);
+        const double cnt = (double)pxg, mean = t1 / cnt;
+        double var = t2 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)a.eps);
+        const float fsc = (float)rstd, fsh = (float)(-mean * rstd);
+        coef[0][tid] = fsc;
+        coef[1][tid] = fsh;
+        if (cc < a.C && band == 0) {
+            const long o = (long)g * a.C + cc;
+            if (a.mean) a.mean[o] = (float)mean;
+            if (a.rstd) a.rstd[o] = (float)rstd;
+            if (a.scale) a.scale[o] = fsc;
+            if (a.shift) a.shift[o] = fsh;
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    float sy[8], ty[8], ss[8], ts[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sy[e] = coef[0][co * 8 + e];
+        ty[e] = coef[1][co * 8 + e];
+        ss[e] = ts[e] = 0.f;
+    }
+    if (a.s) {
+        load8f(a.ss + (long)g * a.C + c, ss);
+        load8f(a.ts + (long)g * a.C + c, ts);
+    }
+    const int Ho = 2 * a.H, Wo = 2 * a.W;
+    const int oy0 = band * a.band, oy1 = oy0 + a.band < Ho ? oy0 + a.band : Ho;
+    auto u_at = [&](int iy, int ix, float (&u)[8]) {
+        const long off = (((long)g * a.H + iy) * a.W + ix) * a.C + c;
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4 *>(a.y + off), v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = fmaf(v[e], sy[e], ty[e]);
+        if (a.s) {
+            unpack8(*reinterpret_cast<const uint4 *>(a.s + off), v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float q = fmaf(v[e], ss[e], ts[e]);
+                u[e] += q > 0.f ? q : 0.2f * q;
+            }
+        }
+    };
+    for (int p = oy0 * Wo + pl; p < oy1 * Wo; p += 32) {
+        const int oy = p / Wo, ox = p - oy * Wo;
+        int y0, y1, x0, x1;
+        float wy0, wy1, wx0, wx1;
+        up_taps2(oy, a.H, y0, y1, wy0, wy1);
+        up_taps2(ox, a.W, x0, x1, wx0, wx1);
+        float u00[8], u01[8], u10[8], u11[8], o[8];
+        u_at(y0, x0, u00);
+        u_at(y0, x1, u01);
+        u_at(y1, x0, u10);
+        u_at(y1, x1, u11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = wy0 * (wx0 * u00[e] + wx1 * u01[e]) + wy1 * (wx0 * u10[e] + wx1 * u11[e]);
+            o[e] = v > 0.f ? v : 0.2f * v;
+        }
+        *reinterpret_cast<uint4 *>(a.out + (((long)g * Ho + oy) * Wo + ox) * a.C + c) = pack8(o);
+    }
+}
+
 constexpr int kFusedMaxRows = 256;     // partial rows a fused workgroup reduces itself (more: stage 1 first)
 constexpr long kFusedMaxDirect = 1024;  // pixels per group the fused kernels reduce without partial rows
 
@@ -613,6 +757,25 @@ extern "C" int combat_norm_add_act_fused(const void *x, const float *partials, i
     return norm_act_fused_launch(x, partials, groups, rows_per_group, px_per_group, C, eps, slope, gamma, beta, mean, rstd,
                                  scale, shift, running_mean, running_var, momentum, num_batches_tracked, scratch,
                                  scratch_bytes, add, add_scale, add_shift, act, stream);
+}
+
+extern "C" int combat_unet_up_fused(const void *y, const float *partials, int32_t rows_per_group, const void *s,
+                                    const float *ss, const float *ts, int32_t N, int32_t H, int32_t W, int32_t C,
+                                    float eps, float *mean, float *rstd, float *scale, float *shift, void *out,
+                                    void *stream) {
+    if (!y || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
+    if (s && (!ss || !ts)) return COMBAT_EINVAL;
+    if (partials ? (rows_per_group <= 0 || rows_per_group > kFusedMaxRows) : (long)H * W > kFusedMaxDirect) return COMBAT_EINVAL;
+    // bands of output rows: enough workgroups to fill the chip, at least 32 output pixels each
+    const int wg_c = (C + 63) / 64, Ho = 2 * H, Wo = 2 * W;
+    int bands = 1;
+    while ((long)N * wg_c * bands < 512 && bands * 2 <= Ho && (Ho / (bands * 2)) * Wo >= 32) bands *= 2;
+    const int band = (Ho + bands - 1) / bands;
+    UpFusedArgs a{reinterpret_cast<const __bf16 *>(y), reinterpret_cast<const __bf16 *>(s), reinterpret_cast<__bf16 *>(out),
+                  partials, partials ? rows_per_group : 0, C, H, W, band, eps, ss, ts, mean, rstd, scale, shift};
+    hipLaunchKernelGGL(unet_up_fused_kernel, dim3(wg_c, (Ho + band - 1) / band, N), dim3(256), 0, as_stream(stream), a);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
 }
 
 extern "C" int combat_norm_bwd_fused(const void *dz, const void *x, const void *add, const float *partials,

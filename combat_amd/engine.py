@@ -1077,11 +1077,19 @@ class UnetEngine(NetEngine):
         t20, s20 = cn("conv2_0", t11, h3, nf * 4, s11, True)
         t21, s21 = cn("conv2_1", t20, h3, nf * 4, s20, True)
         t30, s30 = cn("conv3_0", t21, h4, nf * 8, s21, True)
-        t31, s31 = cn("conv3_1", t30, h4, nf * 8, s30)
+        t31, s31 = cn("conv3_1", t30, h4, nf * 8, s30, True)
 
         def up(level, y, sy, skip, ss, s_in, c):
             o = slot.buf("up%d" % level, (n, 2 * s_in, 2 * s_in, c))
             P.hold(y, skip)
+            if sy.pending is not None:   # y's InstanceNorm is finalised by the launch that upsamples it
+                q = sy.pending
+                sy.pending = None
+                P.hold(q["part"])
+                P.add("up%d.fin" % level, lib.combat_unet_up_fused, y.data_ptr(), _p(q["part"]), q["rpg"], _p(skip),
+                      ss.scale.data_ptr() if ss else None, ss.shift.data_ptr() if ss else None, n, s_in, s_in, c, 1e-5,
+                      sy.mean.data_ptr(), sy.rstd.data_ptr(), sy.scale.data_ptr(), sy.shift.data_ptr(), o.data_ptr())
+                return o
             P.add("up%d" % level, lib.combat_unet_up_fwd, y.data_ptr(), sy.scale.data_ptr(), sy.shift.data_ptr(),
                   _p(skip), ss.scale.data_ptr() if ss else None, ss.shift.data_ptr() if ss else None, n, s_in, s_in, c,
                   o.data_ptr())
@@ -1089,13 +1097,13 @@ class UnetEngine(NetEngine):
 
         u3 = up(3, t31, s31, None, None, h4, nf * 8)
         tu31, su31 = cn("upconv3_1", u3, h3, nf * 8, None, True)
-        tu30, su30 = cn("upconv3_0", tu31, h3, nf * 4, su31)
+        tu30, su30 = cn("upconv3_0", tu31, h3, nf * 4, su31, True)
         u2 = up(2, tu30, su30, t21, s21, h3, nf * 4)
         tu21, su21 = cn("upconv2_1", u2, h2, nf * 4, None, True)
-        tu20, su20 = cn("upconv2_0", tu21, h2, nf * 2, su21)
+        tu20, su20 = cn("upconv2_0", tu21, h2, nf * 2, su21, True)
         u1 = up(1, tu20, su20, t11, s11, h2, nf * 2)
         tu11, su11 = cn("upconv1_1", u1, h1, nf * 2, None, True)
-        tu10, su10 = cn("upconv1_0", tu11, h1, nf, su11)
+        tu10, su10 = cn("upconv1_0", tu11, h1, nf, su11, True)
         u0 = up(0, tu10, su10, t01, s01, h1, nf)
         tu01, su01 = cn("upconv0_1", u0, hw, nf, None)
         rec_conv(P, "upconv0_0", tu01, self.output(slot), pc["upconv0_0"], 0, pro=self._in_aff(su01),

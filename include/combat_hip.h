@@ -296,6 +296,13 @@ int combat_unet_up_fwd(const void *y, const float *sy, const float *ty, const vo
                        const float *ts, int32_t N, int32_t H, int32_t W, int32_t C, void *out, void *stream);
 int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N, int32_t H, int32_t W, int32_t C,
                        void *du, void *stream);
+/* combat_norm_finalize (InstanceNorm, no affine) + combat_unet_up_fwd in one launch, for decoder inputs whose
+ * normalised map is consumed only through the upsample: sy / ty are computed from y's partial rows
+ * ([N * rows_per_group][2][C], rows_per_group <= 256) or, partials == NULL (H*W <= 1024), from y itself, and
+ * published with mean / rstd for the backward pass. */
+int combat_unet_up_fused(const void *y, const float *partials, int32_t rows_per_group, const void *s,
+                         const float *ss, const float *ts, int32_t N, int32_t H, int32_t W, int32_t C, float eps,
+                         float *mean, float *rstd, float *scale, float *shift, void *out, void *stream);
 /* same sum without upsampling (level 0: u1 = IN(upconv1_0) + f0 feeds up() only, but the
  * encoder skip needs d(skip) = du * lrelu'(skip pre-activation) -- handled by conv epilogues) */
 

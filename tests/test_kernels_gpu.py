@@ -858,6 +858,43 @@ def test_unet_up_forward_backward(ops):
     assert rel_l2(nchw(du), uu.grad) < 4e-3
 
 
+@pytest.mark.parametrize("n,hw,c,rows", [(5, 2, 512, 0), (4, 4, 256, 0), (3, 8, 128, 2), (3, 16, 64, 8), (2, 8, 72, 0)])
+def test_unet_up_fused_equals_finalize_plus_upsample(ops, n, hw, c, rows):
+    """combat_unet_up_fused = (group statistics ->) combat_norm_finalize -> combat_unet_up_fwd in one launch:
+    same published InstanceNorm statistics and the same upsampled tensor (bit for bit with partial rows; with
+    the sums taken from the tensor, against torch), with and without the skip operand."""
+    from combat_amd._lib import lib
+    y = torch.randn(n, hw, hw, c, generator=g(180)) * 1.4 + 0.3
+    sk = torch.randn(n, hw, hw, c, generator=g(181))
+    yb, skb = dev(y.to(bf16)), dev(sk.to(bf16))
+    ss, ts = dev(torch.rand(n, c, generator=g(182)) + 0.5), dev(torch.randn(n, c, generator=g(183)) * 0.2)
+    pq = hw * hw
+    mean, rstd, scale, shift = (torch.empty(n, c, device="cuda") for _ in range(4))
+    for skip in (True, False):
+        part = None
+        if rows:
+            part = torch.empty(n * rows, 2, c, device="cuda")
+            ops.group_stats(yb.view(n * pq, c), n * rows, pq // rows, part)
+        out = torch.empty(n, 2 * hw, 2 * hw, c, dtype=bf16, device="cuda")
+        ops.check(lib.combat_unet_up_fused(yb.data_ptr(), part.data_ptr() if rows else None, rows, skb.data_ptr() if skip else None,
+                                           ss.data_ptr() if skip else None, ts.data_ptr() if skip else None, n, hw, hw, c, 1e-5,
+                                           mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream), "combat_unet_up_fused")
+        yr = rb(y).permute(0, 3, 1, 2)
+        u = F.instance_norm(yr, eps=1e-5)
+        if skip:
+            u = u + F.leaky_relu(rb(sk).permute(0, 3, 1, 2) * ss.cpu()[:, :, None, None] + ts.cpu()[:, :, None, None], 0.2)
+        ref = F.leaky_relu(F.interpolate(u, scale_factor=2, mode="bilinear", align_corners=False), 0.2)
+        assert rel_l2(nchw(out), ref) < 4e-3
+        assert rel_l2(mean, yr.mean((2, 3))) < 1e-5
+        if rows:   # the two-launch chain on the same partial rows
+            m2, r2, sc2, sh2 = (torch.empty(n, c, device="cuda") for _ in range(4))
+            ops.norm_finalize(part, n, rows, c, pq, mean=m2, rstd=r2, scale=sc2, shift=sh2)
+            out2 = torch.empty_like(out)
+            ops.unet_up_fwd(yb, sc2, sh2, out2, *((skb, ss, ts) if skip else ()))
+            assert torch.equal(out, out2) and torch.equal(scale, sc2) and torch.equal(shift, sh2) and torch.equal(rstd, r2)
+
+
 # ---------------------------------------------------------------- trigger / augmentation / DCT
 
 
