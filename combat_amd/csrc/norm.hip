@@ -629,6 +629,113 @@ __global__ __launch_bounds__(256) void unet_up_fused_kernel(const UpFusedArgs a)
     }
 }
 
+// Backward of the above: du = adjoint_up(d_out * lrelu'(out)) (stored: the encoder skip paths add it), then the
+// InstanceNorm backward of du w.r.t. y, whose two sums run over the whole image -- so a workgroup owns
+// (64 channels, one image): pass 1 computes, stores and sums du, pass 2 re-reads its own du and applies
+// dx = ca*du + cb*y + cc.  Replaces combat_unet_up_bwd + combat_norm_bwd_fused (sums from the tensors).
+struct UpBwdFusedArgs {
+    const __bf16 *d_out, *out, *y;
+    __bf16 *du, *dx;
+    int C, H, W;
+    const float *mean, *rstd;
+};
+
+__global__ __launch_bounds__(256) void unet_up_bwd_fused_kernel(const UpBwdFusedArgs a) {
+    const int tid = threadIdx.x, co = tid & 7, pl = tid >> 3;
+    const int c = blockIdx.x * 64 + co * 8, g = blockIdx.y;
+    const bool live = c < a.C;
+    const int H = a.H, W = a.W, Ho = 2 * H, Wo = 2 * W;
+    const long pxg = (long)H * W;
+    float mu[8], rs[8], f1[8], f2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        mu[e] = f1[e] = f2[e] = 0.f;
+        rs[e] = 1.f;
+    }
+    if (live) {
+        load8f(a.mean + (long)g * a.C + c, mu);
+        load8f(a.rstd + (long)g * a.C + c, rs);
+        for (long i = pl; i < pxg; i += 32) {
+            const int iy = (int)(i / W), ix = (int)(i - (long)iy * W);
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int oy = 2 * iy - 1; oy <= 2 * iy + 2; ++oy) {
+                if (oy < 0 || oy >= Ho) continue;
+                int y0, y1;
+                float wy0, wy1;
+                up_taps2(oy, H, y0, y1, wy0, wy1);
+                const float wy = (y0 == iy ? wy0 : 0.f) + (y1 == iy ? wy1 : 0.f);
+                if (wy == 0.f) continue;
+                for (int ox = 2 * ix - 1; ox <= 2 * ix + 2; ++ox) {
+                    if (ox < 0 || ox >= Wo) continue;
+                    int x0, x1;
+                    float wx0, wx1;
+                    up_taps2(ox, W, x0, x1, wx0, wx1);
+                    const float wx = (x0 == ix ? wx0 : 0.f) + (x1 == ix ? wx1 : 0.f);
+                    if (wx == 0.f) continue;
+                    const long off = (((long)g * Ho + oy) * Wo + ox) * a.C + c;
+                    float gv[8], o[8];
+                    unpack8(*reinterpret_cast<const uint4 *>(a.d_out + off), gv);
+                    unpack8(*reinterpret_cast<const uint4 *>(a.out + off), o);
+                    const float wgt = wy * wx;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt * (o[e] > 0.f ? 1.f : 0.2f), gv[e], acc[e]);
+                }
+            }
+            const long off = ((long)g * pxg + i) * a.C + c;
+            const uint4 packed = pack8(acc);
+            *reinterpret_cast<uint4 *>(a.du + off) = packed;
+            float dv[8], xv[8];
+            unpack8(packed, dv);               // the sums see the stored (bf16) values, as the two-launch form did
+            unpack8(*reinterpret_cast<const uint4 *>(a.y + off), xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                f1[e] += dv[e];
+                f2[e] = fmaf(dv[e], (xv[e] - mu[e]) * rs[e], f2[e]);
+            }
+        }
+    }
+    double s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        s1[e] = (double)f1[e];
+        s2[e] = (double)f2[e];
+    }
+    __shared__ double sums[4][8][16];
+    __shared__ float coef[3][64];
+    fused_combine(s1, s2, tid, sums);
+    if (tid < 64) {
+        const int cc = blockIdx.x * 64 + tid;
+        double t1, t2;
+        fused_channel_sums(sums, tid, t1, t2);
+        const bool ok = cc < a.C;
+        const double mean = ok ? (double)a.mean[(long)g * a.C + cc] : 0.0, rstd = ok ? (double)a.rstd[(long)g * a.C + cc] : 1.0;
+        const double m1 = t1 / (double)pxg, m2 = t2 / (double)pxg;
+        coef[0][tid] = (float)rstd;
+        coef[1][tid] = (float)(-rstd * rstd * m2);
+        coef[2][tid] = (float)(rstd * (mean * rstd * m2 - m1));
+    }
+    __syncthreads();
+    if (!live) return;
+    float ka[8], kb[8], kc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        ka[e] = coef[0][co * 8 + e];
+        kb[e] = coef[1][co * 8 + e];
+        kc[e] = coef[2][co * 8 + e];
+    }
+    for (long i = pl; i < pxg; i += 32) {   // (each lane re-reads the du it stored itself)
+        const long off = ((long)g * pxg + i) * a.C + c;
+        float dv[8], xv[8], o[8];
+        unpack8(*reinterpret_cast<const uint4 *>(a.du + off), dv);
+        unpack8(*reinterpret_cast<const uint4 *>(a.y + off), xv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf(ka[e], dv[e], fmaf(kb[e], xv[e], kc[e]));
+        *reinterpret_cast<uint4 *>(a.dx + off) = pack8(o);
+    }
+}
+
 constexpr int kFusedMaxRows = 256;     // partial rows a fused workgroup reduces itself (more: stage 1 first)
 constexpr long kFusedMaxDirect = 1024;  // pixels per group the fused kernels reduce without partial rows
 
@@ -774,6 +881,20 @@ extern "C" int combat_unet_up_fused(const void *y, const float *partials, int32_
     UpFusedArgs a{reinterpret_cast<const __bf16 *>(y), reinterpret_cast<const __bf16 *>(s), reinterpret_cast<__bf16 *>(out),
                   partials, partials ? rows_per_group : 0, C, H, W, band, eps, ss, ts, mean, rstd, scale, shift};
     hipLaunchKernelGGL(unet_up_fused_kernel, dim3(wg_c, (Ho + band - 1) / band, N), dim3(256), 0, as_stream(stream), a);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_unet_up_bwd_fused(const void *d_out, const void *out, const void *y, const float *mean,
+                                        const float *rstd, int32_t N, int32_t H, int32_t W, int32_t C, void *du,
+                                        void *dx, void *stream) {
+    if (!d_out || !out || !y || !mean || !rstd || !du || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7))
+        return COMBAT_EINVAL;
+    if ((long)H * W > kFusedMaxDirect) return COMBAT_EINVAL;
+    UpBwdFusedArgs a{reinterpret_cast<const __bf16 *>(d_out), reinterpret_cast<const __bf16 *>(out),
+                     reinterpret_cast<const __bf16 *>(y), reinterpret_cast<__bf16 *>(du), reinterpret_cast<__bf16 *>(dx),
+                     C, H, W, mean, rstd};
+    hipLaunchKernelGGL(unet_up_bwd_fused_kernel, dim3((C + 63) / 64, N), dim3(256), 0, as_stream(stream), a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

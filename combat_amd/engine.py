@@ -1153,9 +1153,15 @@ class UnetEngine(NetEngine):
             rec_conv(P, name + ".dgrad", dy, du_full, pcv, 1)
             y, st = t(y_name), stn(y_name)
             du = G("u%d" % level, y)
+            dy_out = G(y_name + ".dx", y)
+            if y.shape[1] * y.shape[2] <= self.FUSED_DIRECT_PX:   # upsample adjoint + InstanceNorm backward, one launch
+                P.hold(du_full, u, y, du, dy_out)
+                P.add("up%d.bwd.norm" % level, lib.combat_unet_up_bwd_fused, du_full.data_ptr(), u.data_ptr(), y.data_ptr(),
+                      st.mean.data_ptr(), st.rstd.data_ptr(), n, y.shape[1], y.shape[2], y.shape[3], du.data_ptr(),
+                      dy_out.data_ptr())
+                return du, dy_out
             P.add("up%d.bwd" % level, lib.combat_unet_up_bwd, du_full.data_ptr(), u.data_ptr(), n, y.shape[1],
                   y.shape[2], y.shape[3], du.data_ptr())
-            dy_out = G(y_name + ".dx", y)
             self._bwd_apply(P, slot, "g." + y_name, du, y, dy_out, st)    # sums taken from du / y directly
             return du, dy_out
 

@@ -296,6 +296,11 @@ int combat_unet_up_fwd(const void *y, const float *sy, const float *ty, const vo
                        const float *ts, int32_t N, int32_t H, int32_t W, int32_t C, void *out, void *stream);
 int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N, int32_t H, int32_t W, int32_t C,
                        void *du, void *stream);
+/* combat_unet_up_bwd + the InstanceNorm backward of its result w.r.t. y (combat_norm_bwd_fused with the sums
+ * taken from the tensors) in one launch: du = adjoint_up(d_out * lrelu'(out)) is stored (the encoder skip paths
+ * add it), dx = ca*du + cb*y + cc with the coefficients of y's InstanceNorm (mean / rstd [N][C]).  H*W <= 1024. */
+int combat_unet_up_bwd_fused(const void *d_out, const void *out, const void *y, const float *mean, const float *rstd,
+                             int32_t N, int32_t H, int32_t W, int32_t C, void *du, void *dx, void *stream);
 /* combat_norm_finalize (InstanceNorm, no affine) + combat_unet_up_fwd in one launch, for decoder inputs whose
  * normalised map is consumed only through the upsample: sy / ty are computed from y's partial rows
  * ([N * rows_per_group][2][C], rows_per_group <= 256) or, partials == NULL (H*W <= 1024), from y itself, and

@@ -895,6 +895,25 @@ def test_unet_up_fused_equals_finalize_plus_upsample(ops, n, hw, c, rows):
             assert torch.equal(out, out2) and torch.equal(scale, sc2) and torch.equal(shift, sh2) and torch.equal(rstd, r2)
 
 
+@pytest.mark.parametrize("n,hw,c", [(5, 2, 512), (4, 4, 256), (3, 8, 128), (3, 16, 64), (2, 8, 72)])
+def test_unet_up_bwd_fused_equals_two_launches(ops, n, hw, c):
+    """combat_unet_up_bwd_fused = combat_unet_up_bwd + combat_norm_bwd_fused (sums from the tensors), bit for bit."""
+    from combat_amd._lib import lib
+    d_out = dev(torch.randn(n, 2 * hw, 2 * hw, c, generator=g(190)).to(bf16))
+    out = dev(torch.randn(n, 2 * hw, 2 * hw, c, generator=g(191)).to(bf16))
+    y = dev((torch.randn(n, hw, hw, c, generator=g(192)) * 1.3 + 0.2).to(bf16))
+    mean, rstd = dev(torch.randn(n, c, generator=g(193)) * 0.2), dev(torch.rand(n, c, generator=g(194)) + 0.5)
+    st = torch.cuda.current_stream().cuda_stream
+    du, dx, du2, dx2 = (torch.empty(n, hw, hw, c, dtype=bf16, device="cuda") for _ in range(4))
+    ops.check(lib.combat_unet_up_bwd_fused(d_out.data_ptr(), out.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), n,
+                                           hw, hw, c, du.data_ptr(), dx.data_ptr(), st), "combat_unet_up_bwd_fused")
+    ops.unet_up_bwd(d_out, out, du2)
+    ops.check(lib.combat_norm_bwd_fused(du2.data_ptr(), y.data_ptr(), None, None, n, 0, hw * hw, c, None, mean.data_ptr(),
+                                        rstd.data_ptr(), None, None, None, 0, dx2.data_ptr(), st), "combat_norm_bwd_fused")
+    assert torch.equal(du, du2)
+    assert rel_l2(dx.float(), dx2.float()) < 1e-3 and float((dx.float() - dx2.float()).abs().max()) <= 2 * float(dx2.float().abs().max()) * 2 ** -8
+
+
 # ---------------------------------------------------------------- trigger / augmentation / DCT
 
 
