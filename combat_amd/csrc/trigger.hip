@@ -134,6 +134,7 @@ __global__ __launch_bounds__(256) void trigger_fwd_kernel(const float *__restric
 __global__ __launch_bounds__(256) void trigger_bwd_kernel(const float *__restrict__ x, const __bf16 *__restrict__ noise,
                                                           const float *__restrict__ P, const float *__restrict__ k1,
                                                           float rate, int hw, const float *__restrict__ d_out,
+                                                          const float *__restrict__ d_out2,
                                                           const float *__restrict__ outp, float l2_scale,
                                                           int pre_tanh, __bf16 *__restrict__ d_noise) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(256) void trigger_bwd_kernel(const float *__restric
         A[o] = (float)noise[((long)img * hw2 + o) * 8 + c];
         const long go = ((long)img * 3 + c) * hw2 + o;
         float g = d_out ? d_out[go] : 0.f;
+        if (d_out2) g += d_out2[go];      // a second gradient of the same tensor (another classifier's share)
         if (l2_scale != 0.f) g = fmaf(2.f * l2_scale, outp[go] - xi[o], g);
         G[o] = g;
     }
@@ -338,15 +340,15 @@ extern "C" int combat_trigger_fwd(const float *x, const void *noise, const float
 }
 
 extern "C" int combat_trigger_bwd(const float *x, const void *noise, const float *P, const float *k1,
-                                  float noise_rate, int32_t n, int32_t hw, const float *d_out, const float *out,
-                                  float l2_scale, int32_t pre_tanh, void *d_noise, void *stream) {
+                                  float noise_rate, int32_t n, int32_t hw, const float *d_out, const float *d_out2,
+                                  const float *out, float l2_scale, int32_t pre_tanh, void *d_noise, void *stream) {
     if (!x || !noise || !P || !k1 || !d_noise || n < 0 || hw < 16 || hw > 64 || (hw & 3)) return COMBAT_EINVAL;
     if (l2_scale != 0.f && !out) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     const int bytes = (5 * hw * hw + 2 * hw) * 4;
     if (set_smem(trigger_bwd_kernel, bytes)) return COMBAT_ELAUNCH;
     hipLaunchKernelGGL(trigger_bwd_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x,
-                       reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, d_out, out, l2_scale,
+                       reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, d_out, d_out2, out, l2_scale,
                        pre_tanh, reinterpret_cast<__bf16 *>(d_noise));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;

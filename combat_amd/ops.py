@@ -258,10 +258,10 @@ def trigger_fwd(x, noise, p_mat, k1, noise_rate, out, out_c8=None, mse_partial=N
           "combat_trigger_fwd", str(tuple(x.shape)))
 
 
-def trigger_bwd(x, noise, p_mat, k1, noise_rate, d_out, out, l2_scale, d_noise, pre_tanh=False) -> None:
+def trigger_bwd(x, noise, p_mat, k1, noise_rate, d_out, out, l2_scale, d_noise, pre_tanh=False, d_out2=None) -> None:
     n, _, hw, _ = x.shape
     check(lib.combat_trigger_bwd(x.data_ptr(), noise.data_ptr(), p_mat.data_ptr(), k1.data_ptr(), noise_rate, n, hw,
-                                 _p(d_out), _p(out), l2_scale, int(pre_tanh), d_noise.data_ptr(), _stream()),
+                                 _p(d_out), _p(d_out2), _p(out), l2_scale, int(pre_tanh), d_noise.data_ptr(), _stream()),
           "combat_trigger_bwd", str(tuple(x.shape)))
 
 

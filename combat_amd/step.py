@@ -360,10 +360,10 @@ class AlternatedStep:
             ev_met = torch.cuda.Event()
             ev_met.record()
         torch.cuda.current_stream().wait_event(ev_side)     # ---- join
-        self.d_bd += self.d_bd2
         l2_scale = float(opt.L2_weight) / float(n * 3 * hw * hw)          # :234, :253
-        ops.check(lib.combat_trigger_bwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.d_bd.data_ptr(), bd_ptr,
-                                         l2_scale, 1, self.sG.buf("g.z", (n, hw, hw, 8)).data_ptr(), st), "trigger bwd")
+        ops.check(lib.combat_trigger_bwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.d_bd.data_ptr(),
+                                         self.d_bd2.data_ptr(), bd_ptr, l2_scale, 1,
+                                         self.sG.buf("g.z", (n, hw, hw, 8)).data_ptr(), st), "trigger bwd")   # d_bd + d_bd2
         self._backward_allreduce(pl["G_b"], eG, prof)
         eG.fp.sgd_step(float(lr_g if lr_g is not None else opt.lr_G), grad_scale=1.0 / self.world)
         if not self.keep_grads:

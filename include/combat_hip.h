@@ -326,8 +326,8 @@ int combat_unet_up_fused(const void *y, const float *partials, int32_t rows_per_
 int combat_trigger_fwd(const float *x, const void *noise, const float *P, const float *k1, float noise_rate,
                        int32_t n, int32_t hw, float *out, void *out_c8, float *mse_partial, void *stream);
 int combat_trigger_bwd(const float *x, const void *noise, const float *P, const float *k1, float noise_rate,
-                       int32_t n, int32_t hw, const float *d_out, const float *out, float l2_scale,
-                       int32_t pre_tanh, void *d_noise, void *stream);
+                       int32_t n, int32_t hw, const float *d_out, const float *d_out2 /* NULL, or added to d_out */,
+                       const float *out, float l2_scale, int32_t pre_tanh, void *d_noise, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * PostTensorTransform (utils/dataloader.py:45-60): per-sample crop(pad, integer offset) ->

@@ -431,8 +431,8 @@ def test_alternated_step_vs_oracle(mods, golden, with_aug):
     assert abs(m["clean_model_bd_ba"] - int((cm_pred.argmax(1) == t).sum())) <= 1
     assert abs(m["clean_model_bd_asr"] - int((cm_pred.argmax(1) == bd_t).sum())) <= 1
     (d_bd,) = torch.autograd.grad(loss_ce + 0.8 * cm_loss, leaf)
-    assert rel_l2(st.d_bd.cpu(), d_bd) < 0.25            # un-forced classifiers: mask-flip bound
-    total = (ibd * st.d_bd.cpu()).sum() + 0.02 * F.mse_loss(ibd, x)   # engine's own d_bd as cotangent
+    assert rel_l2((st.d_bd + st.d_bd2).cpu(), d_bd) < 0.25            # un-forced classifiers: mask-flip bound
+    total = (ibd * (st.d_bd + st.d_bd2).cpu()).sum() + 0.02 * F.mse_loss(ibd, x)   # engine's own image gradient (both classifiers' shares) as cotangent
     gr = torch.autograd.grad(total, [pg[k] for k in names_g], allow_unused=True)
     gr = torch.cat([(torch.zeros_like(pg[k]) if a is None else a).reshape(-1) for k, a in zip(names_g, gr)])
     assert rel_l2(flat_grads(st.eG.fp, names_g), gr) < 5e-2    # teacher-forced: pins trigger bwd + UNet bwd

@@ -941,7 +941,7 @@ def test_trigger_forward_backward(ops, hw, sigma):
     l2s = 0.02 / ref.numel()
     (ref * d_out).sum().add(l2s * ((ref - x) ** 2).sum()).backward()
     dn = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
-    ops.trigger_bwd(dev(x), n8, pm, k1, 0.08, dev(d_out), out, l2s, dn)
+    ops.trigger_bwd(dev(x), n8, pm, k1, 0.08, dev(d_out * 0.25), out, l2s, dn, d_out2=dev(d_out * 0.75))   # two shares of one gradient
     assert rel_l2(nchw(dn)[:, :3], nz.grad) < 4e-3
 
 
