@@ -101,7 +101,7 @@ SIGNATURES = {
     "combat_unet_up_bwd_fused": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "combat_unet_up_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_unet_up_bwd": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "combat_trigger_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "combat_trigger_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "combat_trigger_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp, c_f32, c_i32, c_vp, c_vp]),
     "combat_augment_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "combat_augment_bwd": (C.c_int, [c_vp, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),

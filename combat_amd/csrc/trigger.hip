@@ -85,18 +85,20 @@ __device__ __forceinline__ void store_hilo(__bf16 *px8, int c, float v) {   // h
 // B [hw][hw+1].  P is symmetric (D^T diag(mask) D), so P N P^T = (P N) P needs no transposed operand.
 __global__ __launch_bounds__(256) void trigger_fwd_kernel(const float *__restrict__ x, const __bf16 *__restrict__ noise,
                                                           const float *__restrict__ P, const float *__restrict__ k1,
-                                                          float rate, int hw, float *__restrict__ out,
+                                                          float rate, int hw, const int *__restrict__ src_index,
+                                                          float *__restrict__ out,
                                                           __bf16 *__restrict__ out_c8, float *__restrict__ mse) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hw2 = hw * hw, lp = hw + 1, tid = threadIdx.x, c = blockIdx.x, img = blockIdx.y;
+    const long src = src_index ? src_index[img] : img;   // row of x / noise this output image is made from
     float *Pl = sm, *Pr = Pl + hw * lp, *A = Pr + hw2, *B = A + hw2;
     const float kk[3] = {k1[0], k1[1], k1[2]};
-    const float *xi = x + ((long)img * 3 + c) * hw2;
+    const float *xi = x + (src * 3 + c) * hw2;
     for (int o = tid; o < hw2; o += 256) {
         const float pv = P[o];
         Pr[o] = pv;
         Pl[(o / hw) * lp + (o % hw)] = pv;
-        A[o] = (float)noise[((long)img * hw2 + o) * 8 + c];
+        A[o] = (float)noise[(src * hw2 + o) * 8 + c];
     }
     __syncthreads();
     mm4(Pl, lp, A, B, lp, hw, tid);            // B = P N
@@ -326,14 +328,14 @@ int set_smem(K kern, int bytes) {
 }  // namespace
 
 extern "C" int combat_trigger_fwd(const float *x, const void *noise, const float *P, const float *k1,
-                                  float noise_rate, int32_t n, int32_t hw, float *out, void *out_c8,
-                                  float *mse_partial, void *stream) {
+                                  float noise_rate, int32_t n, int32_t hw, const int32_t *src_index, float *out,
+                                  void *out_c8, float *mse_partial, void *stream) {
     if (!x || !noise || !P || !k1 || !out || n < 0 || hw < 16 || hw > 64 || (hw & 3)) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     const int bytes = (4 * hw * hw + 2 * hw) * 4;
     if (set_smem(trigger_fwd_kernel, bytes)) return COMBAT_ELAUNCH;
     hipLaunchKernelGGL(trigger_fwd_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x,
-                       reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, out,
+                       reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, src_index, out,
                        reinterpret_cast<__bf16 *>(out_c8), mse_partial);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;

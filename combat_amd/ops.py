@@ -251,10 +251,12 @@ def unet_up_bwd(d_out, out, du) -> None:
           "combat_unet_up_bwd", str(tuple(du.shape)))
 
 
-def trigger_fwd(x, noise, p_mat, k1, noise_rate, out, out_c8=None, mse_partial=None) -> None:
-    n, _, hw, _ = x.shape
+def trigger_fwd(x, noise, p_mat, k1, noise_rate, out, out_c8=None, mse_partial=None, src_index=None) -> None:
+    """src_index (int32 [n_out], device): output image i is built from row src_index[i] of x and noise."""
+    hw = x.shape[2]
+    n = x.shape[0] if src_index is None else src_index.numel()
     check(lib.combat_trigger_fwd(x.data_ptr(), noise.data_ptr(), p_mat.data_ptr(), k1.data_ptr(), noise_rate, n, hw,
-                                 out.data_ptr(), _p(out_c8), _p(mse_partial), _stream()),
+                                 _p(src_index), out.data_ptr(), _p(out_c8), _p(mse_partial), _stream()),
           "combat_trigger_fwd", str(tuple(x.shape)))
 
 

@@ -132,7 +132,7 @@ class AlternatedStep:
     # ------------------------------------------------------------------ buffers per batch size
     _PER_N = ("inputs", "cat_src", "bd", "d_bd", "d_bd2", "mse", "tab", "tab_f", "tab_i", "k1", "_stage", "_stage_i",
               "d_targets", "sC_train", "sC_eval", "sC_met", "sC_bd", "sK_eval", "sK_bd", "sG", "sF", "pl",
-              "_gen_small")
+              )
 
     def _setup(self, n: int):
         """Buffers, slots and plans are per batch size and cached: the ragged last batch of an epoch
@@ -200,7 +200,6 @@ class AlternatedStep:
         self.pl["K_bd_b"] = eK.backward_eval_plan(self.sK_bd, w_cm)
         if self.sF is not None:
             self.pl["F_f"] = self.eF.forward_plan(self.sF)
-        self._gen_small: Dict[int, tuple] = {}
 
     @staticmethod
     def _table_bytes(n: int) -> int:
@@ -220,15 +219,6 @@ class AlternatedStep:
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
         return self._side
-
-    def _small(self, nbk: int):
-        """Buffers of a poisoned sub-batch bucket: fp32 images, their generator outputs, c8 scratch."""
-        if nbk not in self._gen_small:
-            hw = self.hw
-            self._gen_small[nbk] = (torch.zeros(nbk, 3, hw, hw, dtype=f32, device=self.dev),
-                                    torch.zeros(nbk, hw, hw, 8, dtype=torch.bfloat16, device=self.dev),
-                                    torch.zeros(nbk, hw, hw, 8, dtype=torch.bfloat16, device=self.dev))
-        return self._gen_small[nbk]
 
     # ------------------------------------------------------------------ one step
     def run(self, inputs: torch.Tensor, targets_cpu: torch.Tensor, rnd: Optional[StepRandomness] = None,
@@ -288,13 +278,8 @@ class AlternatedStep:
         ev_fork.record()
 
         # ================= Phase C (train_generator.py:175-212) =================
-        if nb:
-            nbk = min(bucket(nb), n)
-            tochange, noise_small, c8_scratch = self._small(nbk)
-            ops.check(lib.combat_augment_fwd(x_ptr, self.tab_i[0].data_ptr(), None, nbk, hw, c8_scratch.data_ptr(),
-                                             tochange.data_ptr(), st), "gather poisoned")
-            torch.index_select(noise, 0, self.tab_i[0][:nbk], out=noise_small)
-            ops.check(lib.combat_trigger_fwd(tochange.data_ptr(), noise_small.data_ptr(), P_, k1c, rate, nb, hw,
+        if nb:   # the poisoned images: rows index_small[:nb] of the batch and of the generator output (:186-194)
+            ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1c, rate, nb, hw, self.tab_i[0].data_ptr(),
                                              self.cat_src[n:].data_ptr(), None, None, st), "trigger C")
         ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(), aug_ptr[0], n, hw,
                                          eC.input(self.sC_train).data_ptr(), None, st), "augment 0")
@@ -312,7 +297,7 @@ class AlternatedStep:
         bd_ptr = self.bd.data_ptr()
         with torch.cuda.stream(side):
             s2 = side.cuda_stream
-            ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, bd_ptr, None,
+            ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, None, bd_ptr, None,
                                              self.mse.data_ptr(), s2), "trigger G")            # :224-226
             ev_bd = torch.cuda.Event()
             ev_bd.record()
@@ -526,7 +511,7 @@ class ClassifierStep:
                                              self.eG.input(sS).data_ptr(), tochange.data_ptr(), st), "gather poisoned")
             plan_small.run()
             ops.check(lib.combat_trigger_fwd(tochange.data_ptr(), self.eG.output(sS).data_ptr(), self.P.data_ptr(),
-                                             self.k1.data_ptr(), float(opt.noise_rate), nb, hw,
+                                             self.k1.data_ptr(), float(opt.noise_rate), nb, hw, None,
                                              self.cat_src[n:].data_ptr(), None, None, st), "trigger")
         ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(),
                                          self.tab_f.data_ptr() if aug is not None else None, n, hw,

@@ -324,7 +324,9 @@ int combat_unet_up_fused(const void *y, const float *partials, int32_t rows_per_
  * pre-tanh output (networks/models.py:340).
  * ------------------------------------------------------------------------------------------ */
 int combat_trigger_fwd(const float *x, const void *noise, const float *P, const float *k1, float noise_rate,
-                       int32_t n, int32_t hw, float *out, void *out_c8, float *mse_partial, void *stream);
+                       int32_t n, int32_t hw, const int32_t *src_index /* NULL, or output image i is made from row
+                       src_index[i] of x and noise: the poisoned sub-batch, train_generator.py:186-192 */,
+                       float *out, void *out_c8, float *mse_partial, void *stream);
 int combat_trigger_bwd(const float *x, const void *noise, const float *P, const float *k1, float noise_rate,
                        int32_t n, int32_t hw, const float *d_out, const float *d_out2 /* NULL, or added to d_out */,
                        const float *out, float l2_scale, int32_t pre_tanh, void *d_noise, void *stream);

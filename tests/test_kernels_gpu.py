@@ -937,6 +937,11 @@ def test_trigger_forward_backward(ops, hw, sigma):
     assert rel_l2(mse.view(n, 3), ((ref - x) ** 2).sum((2, 3))) < 1e-4
     hi, lo = out8[..., :3].float().cpu(), out8[..., 3:6].float().cpu()
     assert float(((hi + lo).permute(0, 3, 1, 2) - ref).abs().max()) < 3e-5
+    # the poisoned sub-batch: output image i from row src_index[i] of the images and of the generator output
+    idx = torch.tensor([3, 0, 4], dtype=torch.int32)
+    sub = torch.empty(3, 3, hw, hw, device="cuda")
+    ops.trigger_fwd(dev(x), n8, pm, k1, 0.08, sub, src_index=dev(idx))
+    assert torch.equal(sub, out[idx.long().cuda()])
     d_out = torch.randn(n, 3, hw, hw, generator=g(92))
     l2s = 0.02 / ref.numel()
     (ref * d_out).sum().add(l2s * ((ref - x) ** 2).sum()).backward()
