@@ -1154,7 +1154,8 @@ class UnetEngine(NetEngine):
             y, st = t(y_name), stn(y_name)
             du = G("u%d" % level, y)
             dy_out = G(y_name + ".dx", y)
-            if y.shape[1] * y.shape[2] <= self.FUSED_DIRECT_PX:   # upsample adjoint + InstanceNorm backward, one launch
+            if y.shape[1] * y.shape[2] <= 64:   # upsample adjoint + InstanceNorm backward, one launch (one workgroup per
+                # (image, 64 channels): on 16 x 16 maps that is half the chip doing all the work -- two launches there)
                 P.hold(du_full, u, y, du, dy_out)
                 P.add("up%d.bwd.norm" % level, lib.combat_unet_up_bwd_fused, du_full.data_ptr(), u.data_ptr(), y.data_ptr(),
                       st.mean.data_ptr(), st.rstd.data_ptr(), n, y.shape[1], y.shape[2], y.shape[3], du.data_ptr(),
