@@ -89,9 +89,9 @@ def conv_flops(a):
 
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
-    per the gfx950 correction + WRITE_SIZE, separate --pmc runs; profiles/r01_j_pmc_hbm_traffic.csv):
+    per the gfx950 correction + WRITE_SIZE, separate --pmc runs; profiles/r01_k_pmc_hbm_traffic.csv):
     PMC counters cannot be collected from inside this process.  None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_j_pmc_hbm_traffic.csv")
+    path = os.path.join(ROOT, "profiles", "r01_k_pmc_hbm_traffic.csv")
     try:
         tot = cnt = 0.0
         for line in open(path):
@@ -132,7 +132,7 @@ def roofline_from(prof):
         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
         "traffic": pmc_traffic(fam + "<"),
         "traffic_unit": "HBM bytes per launch, launch-weighted over the instantiations (rocprofv3 PMC passes, "
-                        "profiles/r01_j_pmc_hbm_traffic.csv)",
+                        "profiles/r01_k_pmc_hbm_traffic.csv)",
         "kernel": fam + " (all tile instantiations)", "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
         "gflop_per_launch": round(fl / cnt / 1e9, 3),
         "all_conv_tiles": {TILE_NAMES.get(t, str(t)): {"launches": c, "avg_us": round(s_ / c * 1e6, 2),
