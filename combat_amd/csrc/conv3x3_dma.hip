@@ -59,7 +59,9 @@ struct DGeo {
     // halo row pitch in pixels.  The slot rotation is keyed on the halo COLUMN (hx & 6), so a tap's row
     // offset (a multiple of the pitch) never changes it; the 16 pixels of a fragment lie in one halo
     // row (TW 16) or in rows whose equal columns fall into the same rotation class (TW 8), which keeps
-    // ds_read_b128 conflict-free for any pitch.  TW 4 keeps the power-of-two pitch.
+    // ds_read_b128 conflict-free for any pitch.  TW 4 (pitch 8): a fragment is four rows of the same four
+    // columns, so the key is (column bit 1, row parity) there -- with the column key alone every fragment read
+    // was a 2-way bank conflict (LdsBankConflict 0.50 in the PMC pass, 0.03-0.06 on the other geometries).
     static constexpr int HWP = TW == 4 ? 8 : TW + 2;
     static constexpr int HROWS = TI * HH * HWP;                  // LDS rows (pixels) of one halo image
     static constexpr int HPW = (HROWS + 8 * NW - 1) / (8 * NW);  // 1-KiB DMA pieces (8 rows) per wave
@@ -153,7 +155,10 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         const int row = (wid + NW * j) * 8 + (lane >> 3), slot = lane & 7;
         const int hx = row % G::HWP, t = row / G::HWP;
         const int hy = t % G::HH, ti = t / G::HH;
-        const int chunk = (slot - (hx & 6)) & 7;
+        // slot rotation of this halo position (see the fragment reads): by column; on 4-wide maps, where a
+        // fragment's 16 pixels are four rows of the same four columns, by column bit 1 and row parity
+        const int rot = TW == 4 ? ((hx & 2) + ((hy & 1) << 2)) : (hx & 6);
+        const int chunk = (slot - rot) & 7;
         const int img = img0 + ti, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
         const bool ok = row < G::HROWS && hx < TW + 2 && img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         hvoff[j] = ok ? (unsigned)((((img * H + iy) * W + ix) * C + chunk * 8) * 2) : kOob;
@@ -175,7 +180,8 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         const int r0 = (ti * G::HH + ty) * G::HWP + tx;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int s0 = ((lane >> 4) + ((tx + dx) & 6)) & 7;
+            const int rot = TW == 4 ? (((tx + dx) & 2) + ((ty & 1) << 2)) : ((tx + dx) & 6);   // (TW 4: for filter row 0)
+            const int s0 = ((lane >> 4) + rot) & 7;
             pa[0][j][dx] = (r0 + dx) * 128 + s0 * 16;
             pa[1][j][dx] = (r0 + dx) * 128 + (s0 ^ 4) * 16;
         }
@@ -200,8 +206,10 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         constexpr int dy = t / 3, dx = t % 3;
         const unsigned char *hb = halo + hbuf * HBYTES + dy * G::HWP * 128;
         const unsigned char *wb = wring + (t % 3) * WBYTES;
+        // TW 4: an odd filter row flips the row parity of the rotation key = the other k-step's slot (s0 ^ 4)
+        constexpr int kk = (TW == 4 && (dy & 1)) ? (ks ^ 1) : ks;
 #pragma unroll
-        for (int j = 0; j < T::FM; ++j) fp[j] = *reinterpret_cast<const bf16x8_t *>(hb + pa[ks][j][dx]);
+        for (int j = 0; j < T::FM; ++j) fp[j] = *reinterpret_cast<const bf16x8_t *>(hb + pa[kk][j][dx]);
 #pragma unroll
         for (int i = 0; i < T::FN; ++i) fw[i] = *reinterpret_cast<const bf16x8_t *>(wb + wa[ks] + i * 2048);
         __builtin_amdgcn_sched_barrier(0);
