@@ -7,19 +7,30 @@
 
 A "step" is one pass of the hot path (train_generator.py:170-290: Phase C + Phase G, both SGD
 updates, and for N > 1 both gradient all-reduces) over one synthetic CIFAR-10-shaped batch of 128
-images per GPU that is already resident in HBM.  Prints ONE JSON line on rank 0 (contract in the
-task statement): whole-job images/sec, plus
+images per GPU that is already resident in HBM.  `--gpus N` without a torchrun environment starts the
+N ranks itself (a child `python -m torch.distributed.run ...`, spawned before anything touches the GPU).
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job images/sec, plus
 
-  roofline      the dominant kernel (the conv gather-GEMM instantiation with the most device time):
+  roofline      the dominant kernel (the convolution kernel family with the most device time):
                 algorithmic FLOPs of its launches / their HIP-event durations, measured in a second,
                 instrumented replay of the same K steps (events on the launch stream), against the
-                2.5 PFLOP/s dense bf16 MFMA peak;
+                2.5 PFLOP/s dense bf16 MFMA peak; `per_shape` = every PreActResNet18 convolution shape
+                (classifier_models/preact_resnet.py:21,23,27-29,77) x {fwd, dgrad, wgrad}: us, TFLOP/s, frac;
   cpu_baseline  the CPU oracle (oracle/combat_oracle.py, the fp32 restatement of the reference step,
-                as written incl. its discarded work) timed on this host's cores on a bounded sample.
+                as written incl. its discarded work) timed on this host's cores on a bounded sample;
+  pytorch_rocm_baseline
+                the same restatement run by stock PyTorch-ROCm on this GPU (ATen + MIOpen), fp32 and bf16
+                autocast: BASELINE.json configs[1]'s "vs PyTorch-ROCm baseline" row.
+
+Before anything is timed the first two steps at B = 128 (augmentation off, recorded num_bd / sigma) are
+checked against tests/golden/step_b128.npz -- losses recorded from the reference's own modules on the same
+batches and seeds -- and the run aborts on a mismatch: the number is for a shape whose results are checked.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,10 +42,13 @@ sys.path.insert(0, ROOT)
 
 METRIC = "images/sec per alternated generator+surrogate step, CIFAR-10 bs=128, 1/2/4/8 GPU"
 PEAK_BF16_TFLOPS = 2500.0
+PMC_TRAFFIC_CSV = ("r02_pmc_hbm_traffic.csv", "r01_k_pmc_hbm_traffic.csv")   # newest first
 TILE_NAMES = {1: "conv_gemm_kernel<128,128>", 2: "conv_gemm_kernel<128,64>", 3: "conv_gemm_kernel<64,64>",
               4: "conv_gemm_kernel<128,16>", 5: "conv_gemm_kernel<64,128>",
               6: "conv3x3_halo1_kernel<256,64>", 7: "conv3x3_halo1_kernel<128,128>", 8: "conv3x3_halo1_kernel<128,64>",
-              9: "conv3x3_halo_kernel<64,64>", 10: "conv3x3_dma_kernel<64>", 11: "conv3x3_dma_kernel<32>", 12: "conv_gather_dma_kernel<64>", 13: "conv_gather_dma_kernel<32>", 14: "conv3x3_dma_kernel<64,256px>"}
+              9: "conv3x3_halo_kernel<64,64>", 10: "conv3x3_dma_kernel<64>", 11: "conv3x3_dma_kernel<32>",
+              12: "conv_gather_dma_kernel<64>", 13: "conv_gather_dma_kernel<32>", 14: "conv3x3_dma_kernel<64,256px>",
+              15: "conv_c8_kernel"}
 
 
 def log(msg):
@@ -79,6 +93,47 @@ def build_nets(device, dataset="cifar10"):
     return netc.to(device), netg.to(device), clean.to(device), netf.to(device)
 
 
+# --------------------------------------------------------------------------------------------- parity gate
+
+
+def golden_gate(device):
+    """Two alternated steps at the benchmarked shape against the trace recorded from the reference modules
+    (tests/golden/step_b128.npz: bench batches 0 and 1, network seeds 0..3, augmentation off).  Tolerance as
+    in tests/test_engine_gpu.py: 2e-2 * max(1, |ref|) per loss (bf16 activations vs fp32), loss_l2 2 % rel."""
+    from combat_amd import step as step_mod
+    path = os.path.join(ROOT, "tests", "golden", "step_b128.npz")
+    if not os.path.exists(path):
+        return {"checked": False, "why": "tests/golden/step_b128.npz absent"}
+    g = dict(np.load(path))
+    opt = Opt()
+    opt.post_transform_option = "no_use"
+    netc, netg, clean, netf = build_nets(device)
+    st = step_mod.AlternatedStep(netc, netg, clean, netf, opt)
+    batches = synth_batches(2, opt.bs, 0, device)
+    report = {"checked": True, "reference": "tests/golden/step_b128.npz (reference modules, fp32)", "steps": []}
+    ok = True
+    for s in range(2):
+        x, t = batches[s]
+        assert abs(float(x.double().sum()) - float(g["step%d/x_sum" % s])) < 1e-6, "synthetic batch differs from the golden's"
+        st.reset_metrics()
+        st.run(x, t, step_mod.StepRandomness(int(g["num_bd"][s]), float(g["sigma_c"][s]), float(g["sigma_g"][s]), [None] * 5))
+        torch.cuda.synchronize()
+        m = st.read_metrics()
+        row = {}
+        for ours, key, rel in (("loss_c_sum", "loss_c", False), ("loss_ce_sum", "loss_ce", False),
+                               ("clean_model_loss_sum", "clean_model_loss", False), ("loss_l2_sum", "loss_l2", True)):
+            r = float(g["trace/" + key][s])
+            tol = 2e-2 * (abs(r) if rel else max(1.0, abs(r))) * (1.0 if s == 0 else 2.0)   # step 2 starts from two bf16 updates
+            row[key] = [round(m[ours], 6), round(r, 6)]
+            ok = ok and abs(m[ours] - r) < tol
+        report["steps"].append(row)
+    report["ok"] = bool(ok)
+    return report
+
+
+# --------------------------------------------------------------------------------------------- roofline
+
+
 def conv_flops(a):
     """Algorithmic FLOPs of one conv launch: 2 * output pixels of the convolution * Cout * Cin * taps
     with the REAL channel counts (padding channels and the masked taps of a strided dgrad are not work)."""
@@ -87,35 +142,61 @@ def conv_flops(a):
     return 2.0 * pix * pc.K * pc.c_real * pc.taps
 
 
+def wgrad_flops(a):
+    return 2.0 * a.N * a.P * a.Q * a.k_real * a.c_real * a.R * a.S
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
-    per the gfx950 correction + WRITE_SIZE, separate --pmc runs; profiles/r01_k_pmc_hbm_traffic.csv):
-    PMC counters cannot be collected from inside this process.  None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_k_pmc_hbm_traffic.csv")
-    try:
-        tot = cnt = 0.0
-        for line in open(path):
-            if line.startswith("#") or line.startswith("kernel,"):
-                continue
-            f = line.rstrip("\n").rsplit(",", 6)
-            if kernel_prefix in f[0]:
-                tot += float(f[1]) * float(f[6]) * 1024.0
-                cnt += float(f[1])
-        return round(tot / cnt) if cnt else None
-    except OSError:
-        return None
+    per the gfx950 correction + WRITE_SIZE, separate --pmc runs): PMC counters cannot be collected from
+    inside this process.  (bytes, file) or (None, None) if no summary is present."""
+    for name in PMC_TRAFFIC_CSV:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            tot = cnt = 0.0
+            for line in open(path):
+                if line.startswith("#") or line.startswith("kernel,"):
+                    continue
+                f = line.rstrip("\n").rsplit(",", 6)
+                if kernel_prefix in f[0]:
+                    tot += float(f[1]) * float(f[6]) * 1024.0
+                    cnt += float(f[1])
+            if cnt:
+                return round(tot / cnt), name
+        except OSError:
+            continue
+    return None, None
+
+
+def shape_key(src_hw, c, k, r, stride):
+    return "%dx%d s%d %d->%d @%dx%d" % (r, r, stride, c, k, src_hw, src_hw)
 
 
 def roofline_from(prof):
-    from combat_amd._lib import lib
+    from combat_amd._lib import ConvArgs, lib
     import ctypes
-    groups = {}
+    groups, per_shape = {}, {}
     for what, a, e0, e1 in prof:
-        tile = lib.combat_conv_pick_tile(ctypes.byref(a))
-        g = groups.setdefault(tile, [0.0, 0.0, 0])
-        g[0] += conv_flops(a)
-        g[1] += e0.elapsed_time(e1) * 1e-3
-        g[2] += 1
+        sec = e0.elapsed_time(e1) * 1e-3
+        if isinstance(a, ConvArgs):
+            fl = conv_flops(a)
+            tile = lib.combat_conv_pick_tile(ctypes.byref(a))
+            g = groups.setdefault(tile, [0.0, 0.0, 0])
+            g[0] += fl
+            g[1] += sec
+            g[2] += 1
+            pc = a._keepalive[2]
+            # the convolution's input map: src of a forward launch, dst (= dx) of an input-gradient launch
+            key = shape_key(a.H if a.mode == 0 else a.P, pc.c_real, pc.K, pc.R, pc.stride)
+            kind = "fwd" if a.mode == 0 else "dgrad"
+        else:
+            fl = wgrad_flops(a)
+            key, kind = shape_key(a.H, a.c_real, a.k_real, a.R, a.stride), "wgrad"
+        if what.startswith("preact."):
+            d = per_shape.setdefault(key, {}).setdefault(kind, [0.0, 0.0, 0])
+            d[0] += fl
+            d[1] += sec
+            d[2] += 1
     # the dominant kernel = the __global__ template with the most device time, over all its tile
     # instantiations (rocprofv3 lists each instantiation; "all_conv_tiles" below does too)
     fams = {}
@@ -127,24 +208,57 @@ def roofline_from(prof):
         g[2] += c
     fam, (fl, sec, cnt) = max(fams.items(), key=lambda kv: kv[1][1])
     achieved = fl / sec / 1e12
+    traffic, traffic_file = pmc_traffic(fam + "<")
+    shapes = {}
+    for key, kinds in sorted(per_shape.items()):
+        shapes[key] = {kind: {"launches": c, "us": round(s_ / c * 1e6, 2), "tflops": round(f / s_ / 1e12, 1),
+                              "frac": round(f / s_ / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                       for kind, (f, s_, c) in sorted(kinds.items())}
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-        "traffic": pmc_traffic(fam + "<"),
+        "traffic": traffic,
         "traffic_unit": "HBM bytes per launch, launch-weighted over the instantiations (rocprofv3 PMC passes, "
-                        "profiles/r01_k_pmc_hbm_traffic.csv)",
+                        "profiles/%s)" % traffic_file,
         "kernel": fam + " (all tile instantiations)", "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
         "gflop_per_launch": round(fl / cnt / 1e9, 3),
         "all_conv_tiles": {TILE_NAMES.get(t, str(t)): {"launches": c, "avg_us": round(s_ / c * 1e6, 2),
                                                       "tflops": round(f / s_ / 1e12, 1)}
                            for t, (f, s_, c) in sorted(groups.items())},
+        "per_shape": shapes,
+        "per_shape_note": "PreActResNet18 convolutions (surrogate + clean model plans), keyed 'RxS stride Cin->Cout "
+                          "@input HxW'; wgrad = weight-gradient launch incl. its partial-sum reduction launch",
     }
+
+
+# --------------------------------------------------------------------------------------------- baselines
+
+
+def _oracle_state(seed_ctor):
+    return {k: v.clone() for k, v in seed_ctor().state_dict().items()}
+
+
+def _oracle_nets(device=None):
+    from combat_amd import nets
+    out = []
+    for seed, ctor in ((0, nets.PreActResNet18), (1, nets.PreActResNet18), (2, lambda: nets.UnetGenerator(None)),
+                       (3, lambda: nets.FrequencyModel(2, 3, 32))):
+        torch.manual_seed(seed)
+        sd = _oracle_state(ctor)
+        out.append({k: (v.to(device) if device is not None else v) for k, v in sd.items()})
+    return out
+
+
+def _aug_draw(rng, bs):
+    from oracle import combat_oracle as O
+    return O.AugParams(rng.integers(0, 11, bs).astype(np.int32), rng.integers(0, 11, bs).astype(np.int32),
+                       np.where(rng.random(bs) < 0.5, rng.uniform(-10, 10, bs), 0).astype(np.float32),
+                       (rng.random(bs) < 0.5).astype(np.int32))
 
 
 def cpu_baseline(seconds_budget=25.0):
     """The oracle's step, as the reference writes it (loss.backward() into every leaf, all five
     forwards building graphs), fp32, anomaly detection off, on this host's cores."""
-    from combat_amd import nets
     from oracle import combat_oracle as O
     # the GPU box gives one GPU a share of 16 host cores (os.cpu_count() reports the whole host):
     # use the affinity mask, capped at that share, so the CPU leg is not oversubscribed
@@ -154,14 +268,7 @@ def cpu_baseline(seconds_budget=25.0):
         cores = os.cpu_count() or 1
     threads = int(os.environ.get("COMBAT_CPU_THREADS", min(cores, 16)))
     torch.set_num_threads(threads)
-    torch.manual_seed(0)
-    netc = {k: v.clone() for k, v in nets.PreActResNet18().state_dict().items()}
-    torch.manual_seed(1)
-    clean = {k: v.clone() for k, v in nets.PreActResNet18().state_dict().items()}
-    torch.manual_seed(2)
-    netg = {k: v.clone() for k, v in nets.UnetGenerator(None).state_dict().items()}
-    torch.manual_seed(3)
-    netf = {k: v.clone() for k, v in nets.FrequencyModel(2, 3, 32).state_dict().items()}
+    netc, clean, netg, netf = _oracle_nets()
     bufs_c, bufs_g = [None] * len(O.trainable_names(netc)), [None] * len(O.trainable_names(netg))
     g = torch.Generator().manual_seed(1234)
     bs = 128
@@ -169,14 +276,9 @@ def cpu_baseline(seconds_budget=25.0):
     t = torch.randint(0, 10, (bs,), generator=g)
     rng = np.random.default_rng(0)
 
-    def aug():
-        return O.AugParams(rng.integers(0, 11, bs).astype(np.int32), rng.integers(0, 11, bs).astype(np.int32),
-                           np.where(rng.random(bs) < 0.5, rng.uniform(-10, 10, bs), 0).astype(np.float32),
-                           (rng.random(bs) < 0.5).astype(np.int32))
-
     def one():
         n_trg = int((t == 0).sum())
-        rnd = O.StepRandomness(int(np.sum(rng.random(n_trg) < 0.5)), 0.5, 0.6, [aug() for _ in range(5)])
+        rnd = O.StepRandomness(int(np.sum(rng.random(n_trg) < 0.5)), 0.5, 0.6, [_aug_draw(rng, bs) for _ in range(5)])
         O.alternated_step(netc, netg, clean, netf, bufs_c, bufs_g, x, t, rnd, O.StepConfig(), as_written=True)
 
     log("cpu_baseline: %d threads, warm-up step" % threads)
@@ -195,22 +297,90 @@ def cpu_baseline(seconds_budget=25.0):
                       "reference step as written, set_detect_anomaly off" % (steps, el)}
 
 
+def pytorch_rocm_baseline(device, steps=10, budget_s=90.0):
+    """BASELINE.json configs[1] "vs PyTorch-ROCm baseline": the reference step as written (the oracle's
+    functional restatement: same ATen operator sequence as train_generator.py:170-255, all dead work included,
+    anomaly detection off) executed by stock PyTorch-ROCm on this GPU -- convolutions by MIOpen -- in fp32
+    and under bf16 autocast, batched augmentation, same batch / seeds as the HIP path.  A baseline leg: the
+    oracle is the thing timed here, never the product."""
+    from oracle import combat_oracle as O
+    out = {"unit": "images/sec", "kind": "stock PyTorch-ROCm (ATen + MIOpen), reference step as written, 1 GPU",
+           "torch": torch.__version__}
+    bs = 128
+    g = torch.Generator().manual_seed(1234)
+    x = (((torch.randint(0, 256, (bs, 3, 32, 32), generator=g, dtype=torch.uint8).float() / 255) - 0.5) / 0.5).to(device)
+    t = torch.randint(0, 10, (bs,), generator=g).to(device)
+    n_trg = int((t == 0).sum())
+    for tag, autocast in (("fp32", False), ("bf16_autocast", True)):
+        netc, clean, netg, netf = _oracle_nets(device)
+        bufs_c, bufs_g = [None] * len(O.trainable_names(netc)), [None] * len(O.trainable_names(netg))
+        rng = np.random.default_rng(0)
+
+        def one():
+            rnd = O.StepRandomness(int(np.sum(rng.random(n_trg) < 0.5)), 0.5, 0.6, [_aug_draw(rng, bs) for _ in range(5)])
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                O.alternated_step(netc, netg, clean, netf, bufs_c, bufs_g, x, t, rnd, O.StepConfig(), as_written=True,
+                                  aug_fn=O.post_tensor_transform_batched)
+
+        t_start = time.perf_counter()
+        try:
+            for _ in range(3):      # warm-up: MIOpen solver selection / kernel compilation happens here
+                one()
+            torch.cuda.synchronize()
+            warm = time.perf_counter() - t_start
+            log("pytorch_rocm_baseline[%s]: warm-up %.1f s" % (tag, warm))
+            if warm > budget_s:
+                out[tag] = {"value": None, "why": "warm-up alone took %.0f s (MIOpen kernel compilation)" % warm}
+                continue
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out[tag] = {"value": round(bs * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 2), "steps": steps}
+            log("pytorch_rocm_baseline[%s]: %.2f ms/step" % (tag, el / steps * 1e3))
+        except Exception as e:   # a baseline leg must never take the headline measurement down with it
+            out[tag] = {"value": None, "why": "%s: %s" % (type(e).__name__, str(e)[:200])}
+        del netc, clean, netg, netf, bufs_c, bufs_g
+        torch.cuda.empty_cache()
+    return out
+
+
+# --------------------------------------------------------------------------------------------- main
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process (nothing in this
+    process has touched the GPU yet -- a process that has must never exec) and exit with its status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("no torchrun environment: starting %d ranks: %s" % (args.gpus, " ".join(cmd[1:9])))
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-torch-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-golden-gate", action="store_true")
     ap.add_argument("--dataset", default="cifar10", choices=("cifar10", "celeba"),
                     help="cifar10 = BASELINE configs[1] (the metric's configuration); celeba = configs[3]'s shape "
                          "(64 x 64, 8 classes, ResNet18), informational")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -230,6 +400,12 @@ def main():
         pg = torch.distributed.group.WORLD
 
     from combat_amd import step as step_mod
+    gate = None
+    if not args.no_golden_gate and args.dataset == "cifar10" and rank == 0:
+        gate = golden_gate(device)
+        log("golden gate (B=128 vs reference-module trace): %s" % json.dumps(gate))
+        if gate.get("checked") and not gate["ok"]:
+            raise SystemExit("bench.py: results at the benchmarked shape differ from tests/golden/step_b128.npz: %s" % gate)
     opt = Opt()
     if args.dataset == "celeba":
         opt.dataset, opt.input_height, opt.input_width, opt.num_classes = "celeba", 64, 64, 8
@@ -281,14 +457,14 @@ def main():
         from combat_amd.engine import Plan
         prof = []
         st.serial = Plan.serial = True
-        for i in range(args.steps):
+        for i in range(min(args.steps, 20)):
             x, t = batches[i % len(batches)]
             st.run(x, t, prof=prof)
         torch.cuda.synchronize()
         st.serial = Plan.serial = False
         if rank == 0:
             roof = roofline_from(prof)
-            roof["replay"] = "serial (one stream), HIP events around each launch"
+            roof["replay"] = "serial (one stream), HIP events around each convolution / weight-gradient launch, %d steps" % min(args.steps, 20)
             log("instrumented replay done: %s %.1f TFLOP/s" % (roof["kernel"], roof["achieved"]))
     if world > 1:
         torch.distributed.barrier()
@@ -304,7 +480,8 @@ def main():
                                    "Nesterov-SGD updates), bs=128 per GPU, on-device augmentation on",
                        "per_gpu_batch": opt.bs, "global_batch": opt.bs * world,
                        "parallelism": "dp%d (RCCL all-reduce of netC grads in Phase C, netG grads in Phase G)" % world,
-                       "gflop_per_image_algorithmic": 11.67, "losses_finite": finite},
+                       "gflop_per_image_algorithmic": 11.67, "losses_finite": finite,
+                       "golden_gate": gate},
             "roofline": roof,
         }
         if args.dataset != "cifar10":
@@ -312,8 +489,13 @@ def main():
                                          "step at 64 x 64, 8 classes, bs=128 per GPU (informational; the metric's "
                                          "configuration is cifar10)")
             out["config"].pop("gflop_per_image_algorithmic", None)
-        if world == 1 and not args.no_cpu_baseline and args.dataset == "cifar10":
-            out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and args.dataset == "cifar10":
+            del st, netc, netg, clean, netf
+            torch.cuda.empty_cache()
+            if not args.no_torch_baseline:
+                out["pytorch_rocm_baseline"] = pytorch_rocm_baseline(device)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -3,7 +3,8 @@
 get the reference's ToTensor + Normalize(0.5, 0.5) ((u8/255 - 0.5)/0.5), batches come out as pinned
 float32 [B,3,32,32] + int64 labels on the HOST, as a torch DataLoader would yield them.  The whole
 set (150 MB of uint8) stays in RAM, so there are no worker processes; shuffling draws one
-``torch.randperm`` per epoch from torch's global generator like DataLoader's RandomSampler.  Nothing is
+``torch.randperm`` per epoch from a private generator whose base seed comes from torch's global generator
+(DataLoader's RandomSampler does the same).  Nothing is
 downloaded: a missing dataset is an error unless ``--synthetic`` asks for CIFAR-10-shaped noise."""
 from __future__ import annotations
 
@@ -65,29 +66,60 @@ def synthetic_cifar10(n: int, seed: int, hw: int = 32, classes: int = 10) -> Tup
 
 class ArrayLoader:
     """Minimal DataLoader stand-in over in-memory uint8 images: ``len()`` = batches per epoch, iteration
-    yields (inputs, targets[, poisoned]).  ``rank``/``world`` give each data-parallel rank a disjoint
-    strided shard of every epoch's permutation (same permutation on all ranks: seed it identically)."""
+    yields (inputs, targets[, poisoned]).
+
+    Data parallel (``rank``/``world``): every epoch's permutation comes from a PRIVATE ``torch.Generator``
+    seeded ``base_seed + epoch`` -- the same on every rank whatever the ranks have drawn from their global
+    generators in between (augmentation and blur draws are rank-local and would desynchronise a shared
+    stream) -- and rank r takes ``order[r::world]``: disjoint shards of one permutation.  ``base_seed``
+    defaults to a draw from the global generator at construction (the unseeded behaviour of DataLoader's
+    RandomSampler); with a process group it is rank 0's draw.  A shuffling (training) loader gives EVERY
+    rank the same number of samples, hence of batches -- a rank that ran one step more would wait forever
+    in its gradient all-reduce: the permutation is padded by wrapping around, like
+    ``DistributedSampler(drop_last=False)``.  A non-shuffling (evaluation) loader keeps the exact, possibly
+    uneven, strided shards: its loop contains no collective and its counters must not count a sample twice."""
 
     def __init__(self, images: np.ndarray, labels: np.ndarray, bs: int, shuffle: bool, poisoned: Optional[np.ndarray] = None,
-                 rank: int = 0, world: int = 1, drop_last: bool = False):
+                 rank: int = 0, world: int = 1, drop_last: bool = False, base_seed: Optional[int] = None):
         self.x = torch.from_numpy(np.ascontiguousarray(images))
         self.y = torch.from_numpy(np.ascontiguousarray(labels))
         self.poisoned = None if poisoned is None else torch.from_numpy(poisoned.astype(np.bool_))
         self.bs, self.shuffle, self.rank, self.world, self.drop_last = bs, shuffle, rank, world, drop_last
         self.dataset = self  # len(loader.dataset)
+        if base_seed is None:
+            base_seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            if world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+                box = [base_seed]
+                torch.distributed.broadcast_object_list(box, src=0)
+                base_seed = int(box[0])
+        self.base_seed, self.epoch = int(base_seed), 0
 
     def _count(self) -> int:
+        """Samples this rank walks per epoch."""
         n = self.x.shape[0]
-        return (n - self.rank + self.world - 1) // self.world
+        if self.shuffle:
+            return (n + self.world - 1) // self.world          # same on every rank (wrap-around padding)
+        return (n - self.rank + self.world - 1) // self.world   # exact strided shard
 
     def __len__(self) -> int:
         n = self._count()
         return n // self.bs if self.drop_last else (n + self.bs - 1) // self.bs
 
-    def __iter__(self) -> Iterator:
+    def epoch_order(self, epoch: int) -> torch.Tensor:
+        """This rank's sample indices of `epoch` (deterministic in base_seed, epoch, rank, world)."""
         n = self.x.shape[0]
-        order = torch.randperm(n) if self.shuffle else torch.arange(n)
-        order = order[self.rank::self.world]
+        if not self.shuffle:
+            return torch.arange(n)[self.rank::self.world]
+        g = torch.Generator().manual_seed(self.base_seed + epoch)
+        order = torch.randperm(n, generator=g)
+        total = self._count() * self.world
+        if total > n:
+            order = torch.cat([order, order[: total - n]])
+        return order[self.rank::self.world]
+
+    def __iter__(self) -> Iterator:
+        order = self.epoch_order(self.epoch)
+        self.epoch += 1
         for i in range(len(self)):
             idx = order[i * self.bs:(i + 1) * self.bs]
             xb = ((self.x[idx].float() / 255.0) - 0.5) / 0.5
@@ -127,4 +159,9 @@ def get_dataloader(opt, train: bool = True, pretensor_transform: bool = False, b
     if getattr(opt, "debug", False):                         # utils/dataloader.py:118-119
         x, y = x[:1000], y[:1000]
     flags = poison_flags(y, opt, opt.num_classes) if poisoned else None
-    return ArrayLoader(x, y, bs, shuffle, flags, rank, world)
+    if flags is not None and world > 1 and torch.distributed.is_initialized():
+        box = [flags]     # ONE poisoned index set (utils/dataloader_cleanbd.py:142-150 draws it once per dataset): rank 0's
+        torch.distributed.broadcast_object_list(box, src=0)
+        flags = box[0]
+    seed = getattr(opt, "seed", None)
+    return ArrayLoader(x, y, bs, shuffle, flags, rank, world, base_seed=None if seed is None else int(seed) + 7919)

@@ -88,3 +88,28 @@ def all_reduce_counters(values: Sequence[float], group=None, device=None) -> Lis
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     dist.all_reduce(t, group=group)
     return t.tolist()
+
+
+def barrier(group=None) -> None:
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)
+
+
+def fresh_start(folder: str, rank: int, group=None) -> None:
+    """The reference wipes the checkpoint folder on a fresh start (train_generator.py:562).  With several
+    ranks only rank 0 may do that, and nobody may create files under it (log_dir, writers) before the
+    wipe has finished: wipe on rank 0, barrier, then continue."""
+    import shutil
+    if rank == 0:
+        shutil.rmtree(folder, ignore_errors=True)
+    barrier(group)
+
+
+class NullWriter:
+    """SummaryWriter call shape that records nothing (ranks other than 0)."""
+
+    def add_scalars(self, *a, **k):
+        pass
+
+    def add_image(self, *a, **k):
+        pass

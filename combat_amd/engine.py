@@ -64,8 +64,9 @@ class Plan:
         self.marks[len(self.calls) - 1] = grad_offset
 
     def run(self, prof: Optional[list] = None, on_mark=None) -> None:
-        """Replay.  `prof` (a list) switches on per-launch HIP-event bracketing of the convolution
-        kernels on the launch stream: it receives (plan/what, ConvArgs, start_event, end_event).
+        """Replay.  `prof` (a list) switches on per-launch HIP-event bracketing of the convolution and
+        weight-gradient launches on the launch stream: it receives (plan/what, ConvArgs | WgradArgs,
+        start_event, end_event).
         `on_mark(offset)` is called right after the call that completes the gradients above `offset`
         has been enqueued (data-parallel bucketed all-reduce overlapping the rest of the backward)."""
         stream = torch.cuda.current_stream()
@@ -73,7 +74,7 @@ class Plan:
         aux = _aux_stream(stream) if self.aux and not Plan.serial else None
         aux_used = False
         for ci, (cfunc, args, what) in enumerate(self.calls):
-            if prof is not None and cfunc is lib.combat_conv_gemm:
+            if prof is not None and (cfunc is lib.combat_conv_gemm or cfunc is lib.combat_conv_wgrad):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 rc = cfunc(*args, st)
@@ -279,7 +280,7 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
         a.pro_scale, a.pro_shift = _p(pro.scale), _p(pro.shift)
         a.pro_group_stride, a.pro_act, a.pro_slope = pro.group_stride, int(pro.act), pro.slope
     a.split = 0
-    ws = _wgrad_workspace(src.device)
+    ws = _wgrad_workspace(src.device, aux)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     plan.hold(a, src, dy, dw, pro, ws)
     plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a), aux=aux)
@@ -288,14 +289,18 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
 _WGRAD_WS: Dict = {}
 
 
-def _wgrad_workspace(device) -> torch.Tensor:
-    """One scratch buffer per device for the weight-gradient partial sums (launches on a stream run one
-    after the other): pixel ranges x tiles <= ~256 + tiles slabs of 147 KB.  A launch that would need more
-    falls back to fp32 atomics by itself."""
-    ws = _WGRAD_WS.get(device)
+def _wgrad_workspace(device, aux: bool = True) -> torch.Tensor:
+    """Scratch for the weight-gradient partial sums (pixel ranges x tiles <= ~256 + tiles slabs of 147 KB; a
+    launch that would need more falls back to fp32 atomics by itself).  One buffer per device AND per queue
+    the launch is recorded for: launches of one queue run one after the other, but the last weight gradient of
+    a backward plan (aux=False) runs on the plan's own stream while its predecessors may still be writing /
+    reducing their slabs on the auxiliary stream -- sharing one base pointer between the two queues let those
+    launches overwrite each other's partial sums."""
+    key = (device, bool(aux))
+    ws = _WGRAD_WS.get(key)
     if ws is None:
-        ws = torch.empty(48 << 20, dtype=torch.uint8, device=device)
-        _WGRAD_WS[device] = ws
+        ws = torch.empty((48 << 20) if aux else (16 << 20), dtype=torch.uint8, device=device)
+        _WGRAD_WS[key] = ws
     return ws
 
 

@@ -455,11 +455,24 @@ class ClassifierStep:
         self.k1 = torch.zeros(3, dtype=f32, device=self.dev)
         self.transforms = PostTensorTransform(opt)
         self.N = 0
+        self._sets: Dict[int, dict] = {}
         self._small: Dict[int, tuple] = {}
         self._reducer = None
 
+    _PER_N = ("cat_src", "tab_i", "tab_f", "slot", "fwd", "bwd")
+
     def _setup(self, n):
+        """Buffers, slot and plans are per batch size and cached (as AlternatedStep._setup): the ragged last
+        batch of an epoch gets its own set once, and the loss / accuracy cells of every set survive until
+        `read_metrics` sums (and resets) them all."""
         if n == self.N:
+            return
+        if self.N:
+            self._sets[self.N] = {k: getattr(self, k) for k in self._PER_N}
+        if n in self._sets:
+            for k, v in self._sets[n].items():
+                setattr(self, k, v)
+            self.N = n
             return
         self.N, hw, dev = n, self.hw, self.dev
         self.cat_src = torch.zeros(2 * n, 3, hw, hw, dtype=f32, device=dev)
@@ -523,10 +536,18 @@ class ClassifierStep:
         self.eC.fp.sgd_step(float(lr if lr is not None else opt.lr_C), grad_scale=1.0 / self.world)
         self.eC.mark_weights_dirty()
 
+    def _slots(self):
+        out = [self.slot] if self.N else []
+        return out + [d["slot"] for n, d in self._sets.items() if n != self.N]
+
     def read_metrics(self, reset=False):
-        h = self.eC.head_bufs(self.slot)
-        out = {"loss_sum": float(h["loss"]), "correct": int(h["correct"][0])}
-        if reset:
-            h["loss"].zero_()
-            h["correct"].zero_()
+        """Running loss sum / correct count over every batch size run since the last reset (one host sync)."""
+        out = {"loss_sum": 0.0, "correct": 0}
+        for slot in self._slots():
+            h = self.eC.head_bufs(slot)
+            out["loss_sum"] += float(h["loss"])
+            out["correct"] += int(h["correct"][0])
+            if reset:
+                h["loss"].zero_()
+                h["correct"].zero_()
         return out

@@ -55,7 +55,7 @@ def main():
         if not os.path.exists(path):
             print("Error: {} not found".format(path))
             exit()
-        net.load_state_dict(torch.load(path, map_location=opt.device, weights_only=False)[key])
+        net.load_state_dict(torch.load(path, map_location=opt.device, weights_only=True)[key])
         net.eval()
     eval(netC, netG, test_dl, SummaryWriter(log_dir=opt.log_dir), opt)
 

@@ -12,6 +12,9 @@ import torch.nn.functional as F
 
 bf16 = torch.bfloat16
 
+ROUND = True   # False: no bf16 rounding anywhere -- the emulation must then BE the fp32 oracle (dataflow pin:
+#                tests/test_oracle_golden.py::test_bf16_emulation_without_rounding_is_the_oracle)
+
 
 def q(t, force=None, key=None):
     """Round to bf16, identity gradient.  With ``force[key]`` given (the tensor the HIP engine
@@ -20,6 +23,8 @@ def q(t, force=None, key=None):
     exactly the engine's and a gradient comparison is not dominated by mask flips."""
     if force is not None and key in force:
         return t + (force[key] - t).detach()
+    if not ROUND:
+        return t
     return t + (t.to(bf16).float() - t).detach()
 
 

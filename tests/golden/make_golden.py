@@ -220,11 +220,10 @@ def _low_freq(x, ratio=0.65):
     return ref_dct.idct_2d(d) / 255 * 2 - 1
 
 
-def golden_step():
-    """Three alternated steps driven through the reference nn.Modules + torch.optim.SGD in the
-    order of train_generator.py:170-255 (B=16, no augmentation, recorded num_bd / sigma)."""
-    out = {}
-    b, steps = 16, 3
+def _alternated_trace(out, b, steps, batches, num_bds, sig_c, sig_g, record_inputs, final=True, lr=1e-2):
+    """`steps` alternated steps driven through the reference nn.Modules + torch.optim.SGD in the order of
+    train_generator.py:170-255 (no augmentation = --post_transform_option no_use, recorded num_bd / sigma;
+    Gaussian blur restated: torchvision is absent).  batches(s) -> (inputs, targets) of step s."""
     torch.manual_seed(0)
     netc = PreActResNet18()
     torch.manual_seed(1)
@@ -234,21 +233,18 @@ def golden_step():
     torch.manual_seed(3)
     netf = FrequencyModel(num_classes=2, n_input=3, input_size=32).eval()
     out["seeds"] = np.array([0, 1, 2, 3])
-    opt_c = torch.optim.SGD(netc.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
-    opt_g = torch.optim.SGD(netg.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
-    num_bds = [2, 0, 3]
-    sig_c = [0.35, 0.8, 0.55]
-    sig_g = [0.9, 0.2, 0.65]
+    opt_c = torch.optim.SGD(netc.parameters(), lr, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    opt_g = torch.optim.SGD(netg.parameters(), lr, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    out["lr"] = np.float64(lr)
     out["num_bd"], out["sigma_c"], out["sigma_g"] = np.array(num_bds), np.array(sig_c), np.array(sig_g)
     trace = {k: [] for k in ("loss_c", "loss_ce", "loss_l2", "loss_grad_l2", "clean_model_loss", "clean_correct",
                              "bd_correct", "f_correct", "clean_model_correct", "clean_model_bd_ba",
-                             "clean_model_bd_asr", "gnorm_c", "gnorm_g")}
+                             "clean_model_bd_asr", "gnorm_c", "gnorm_g", "train_correct")}
     ce = torch.nn.CrossEntropyLoss()
     for s in range(steps):
-        inputs = synth_images(b, 32, 1234 + s)
-        targets = torch.randint(0, 10, (b,), generator=rng(4321 + s))
-        targets[: 4] = 0  # make sure the target class is present
-        out["step%d/inputs" % s], out["step%d/targets" % s] = inputs.numpy(), targets.numpy()
+        inputs, targets = batches(s)
+        if record_inputs:
+            out["step%d/inputs" % s], out["step%d/targets" % s] = inputs.numpy(), targets.numpy()
         bd_targets = torch.zeros_like(targets)
         netg.eval(); clean.eval(); netc.train(); opt_c.zero_grad()
         trg = (targets == bd_targets).nonzero()[:, 0]
@@ -263,22 +259,26 @@ def golden_step():
             ibd = _blur(ibd, sig_c[s])
         tot_in = torch.cat([ibd, inputs[trg[nb:]], inputs[ntrg]], 0)
         tot_t = torch.cat([bd_targets[trg[:nb]], targets[trg[nb:]], targets[ntrg]], 0)
-        loss_c = ce(netc(tot_in), tot_t)
+        tot_preds = netc(tot_in)
+        loss_c = ce(tot_preds, tot_t)
         loss_c.backward()
         trace["gnorm_c"].append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in netc.parameters()))))
         opt_c.step()
-        clean_preds = clean(inputs)
+        with torch.no_grad():
+            clean_preds = clean(inputs)
         netc.eval(); netg.train(); opt_g.zero_grad()
         noise = _low_freq(netg(inputs))
         ibd = _blur(torch.clamp(inputs + noise * 0.08, -1, 1), sig_g[s])
-        pred_clean = netc(inputs)
+        with torch.no_grad():
+            pred_clean = netc(inputs)
         pred_bd = netc(ibd)
         loss_ce = ce(pred_bd, bd_targets)
         loss_l2 = F.mse_loss(ibd, inputs)
         e, eb = F.pad(inputs, (1, 1, 2, 1)), F.pad(ibd, (1, 1, 2, 1))
         loss_grad_l2 = F.mse_loss(e[:, :, 1:] - e[:, :, :-1], eb[:, :, 1:] - eb[:, :, :-1]) + \
             F.mse_loss(e[:, :, :, 1:] - e[:, :, :, :-1], eb[:, :, :, 1:] - eb[:, :, :, :-1])
-        pred_f = netf(ref_dct.dct_2d(((ibd + 1) / 2 * 255).byte()))
+        with torch.no_grad():
+            pred_f = netf(ref_dct.dct_2d(((ibd + 1) / 2 * 255).byte()))
         cm_preds = clean(ibd)
         cm_loss = ce(cm_preds, targets)
         loss = loss_ce + 0.02 * loss_l2 + 0.8 * cm_loss
@@ -288,18 +288,191 @@ def golden_step():
         for k, v in (("loss_c", loss_c), ("loss_ce", loss_ce), ("loss_l2", loss_l2), ("loss_grad_l2", loss_grad_l2),
                      ("clean_model_loss", cm_loss)):
             trace[k].append(float(v))
+        trace["train_correct"].append(int((tot_preds.argmax(1) == tot_t).sum()))
         trace["clean_correct"].append(int((pred_clean.argmax(1) == targets).sum()))
         trace["bd_correct"].append(int((pred_bd.argmax(1) == bd_targets).sum()))
         trace["f_correct"].append(int((pred_f.argmax(1) == 1).sum()))
         trace["clean_model_correct"].append(int((clean_preds.argmax(1) == targets).sum()))
         trace["clean_model_bd_ba"].append(int((cm_preds.argmax(1) == targets).sum()))
         trace["clean_model_bd_asr"].append(int((cm_preds.argmax(1) == bd_targets).sum()))
-        out["step%d/inputs_bd" % s] = ibd.detach().numpy()
+        if record_inputs:
+            out["step%d/inputs_bd" % s] = ibd.detach().numpy()
+        if s % 10 == 9:
+            print("  step %d: loss_c %.4f loss_ce %.4f cm %.4f l2 %.5f" % (s + 1, trace["loss_c"][-1], trace["loss_ce"][-1],
+                                                                         trace["clean_model_loss"][-1], trace["loss_l2"][-1]), flush=True)
     for k, v in trace.items():
         out["trace/" + k] = np.array(v, dtype=np.float64)
-    summarize(netc.state_dict().items(), out, "final/netc")
-    summarize(netg.state_dict().items(), out, "final/netg")
+    if final:
+        summarize(netc.state_dict().items(), out, "final/netc")
+        summarize(netg.state_dict().items(), out, "final/netg")
+
+
+def golden_step():
+    """Three alternated steps (B=16, inputs recorded)."""
+    out = {}
+
+    def batches(s):
+        inputs = synth_images(16, 32, 1234 + s)
+        targets = torch.randint(0, 10, (16,), generator=rng(4321 + s))
+        targets[: 4] = 0  # make sure the target class is present
+        return inputs, targets
+
+    _alternated_trace(out, 16, 3, batches, [2, 0, 3], [0.35, 0.8, 0.55], [0.9, 0.2, 0.65], True)
     save("step.npz", out)
+
+
+def bench_batch(i, bs=128, rank=0, n_batches=8):
+    """Batch i of bench.py's synthetic pool (bench.py::synth_batches: ONE generator seeded 1234 + rank draws
+    pixels and labels of the 8 batches in turn) -- inputs are regenerated from the seed, not stored."""
+    g = torch.Generator().manual_seed(1234 + rank)
+    out = None
+    for j in range(i % n_batches + 1):
+        u8 = torch.randint(0, 256, (bs, 3, 32, 32), generator=g, dtype=torch.uint8)
+        t = torch.randint(0, 10, (bs,), generator=g)
+        out = (((u8.float() / 255) - 0.5) / 0.5, t)
+    return out
+
+
+def golden_step_b128():
+    """The benchmarked shape: two alternated steps at B=128 on bench.py's own first two batches and network
+    seeds (augmentation off, recorded num_bd / sigma).  Inputs are not stored (checksums pin the generator)."""
+    out = {}
+    n_trg = [int((bench_batch(s)[1] == 0).sum()) for s in range(2)]
+    num_bds = [min(7, n_trg[0]), min(5, n_trg[1])]
+    _alternated_trace(out, 128, 2, bench_batch, num_bds, [0.45, 0.7], [0.6, 0.85], False, final=False)
+    for s in range(2):
+        x, t = bench_batch(s)
+        out["step%d/x_sum" % s] = np.float64(x.double().sum())
+        out["step%d/x_sample" % s] = x.flatten()[:: 9973][:32].numpy()
+        out["step%d/targets" % s] = t.numpy()
+    save("step_b128.npz", out)
+
+
+def golden_trajectory(lr=1e-2, name="trajectory.npz"):
+    """100 alternated steps at B=32 cycling over POOL = 25 fixed batches (four passes over 800 images: the
+    surrogate's loss moves without collapsing to zero), augmentation off, num_bd drawn Binomial(|target class|, 0.5) from a seeded generator and recorded, sigma recorded:
+    the loss / counter curves the HIP path's trajectory test is compared with (100-step loss
+    curves within 2 % after EMA)."""
+    out = {}
+    steps, b = 100, 32
+    POOL = 25
+    pool = [(synth_images(b, 32, 7000 + i), torch.randint(0, 10, (b,), generator=rng(7100 + i))) for i in range(POOL)]
+    g = np.random.default_rng(99)
+    num_bds = [int((g.random(int((pool[s % POOL][1] == 0).sum())) < 0.5).sum()) for s in range(steps)]
+    sig_c = g.uniform(0.1, 1.0, steps).round(4).tolist()
+    sig_g = g.uniform(0.1, 1.0, steps).round(4).tolist()
+    _alternated_trace(out, b, steps, lambda s: pool[s % POOL], num_bds, sig_c, sig_g, False, final=True, lr=lr)
+    out["pool_seeds"], out["pool"] = np.array([7000, 7100]), np.int64(POOL)
+    save(name, out)
+
+
+def golden_trajectory_lr2e3():
+    """The same 100 steps with --lr_C 2e-3 --lr_G 2e-3.  At the default 1e-2 the reference's OWN fp32 run on
+    these synthetic random-label batches turns chaotic after ~45 steps (loss_ce alternates between 0 and
+    50-290 from step 54 on: eval-mode BatchNorm statistics of a net trained 50 steps on noise, probed with
+    un-blurred images whenever sigma_g is small) -- no finite-precision realisation follows that pointwise,
+    so the 100-step comparison is made where the dynamics are smooth, and the default-lr trace is compared
+    over its smooth first 40 steps."""
+    golden_trajectory(2e-3, "trajectory_lr2e3.npz")
+
+
+def randomize_bn_buffers(net, seed):
+    """Non-trivial BatchNorm running statistics for eval-mode fixtures, reproducible from the seed alone (the
+    tests apply the same calls to combat_amd's mirror modules: same module order)."""
+    i = 0
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.05, generator=rng(seed + i))
+                m.running_var.uniform_(0.6, 1.4, generator=rng(seed + 1000 + i))
+                i += 1
+    return net
+
+
+def golden_eval_victim():
+    """Counters of the reference's evaluation loop body (train_generator.py:353-391 = eval.py:119-143 +
+    detector / clean-model rows) on two synthetic test batches, and one batch of train_victim.py:102-141
+    (D3 intent: ntrg = ~poisoned) / train_clean_classifier.py:87-110, all through the reference modules."""
+    out = {}
+    torch.manual_seed(0)
+    netc = randomize_bn_buffers(PreActResNet18(), 500)
+    torch.manual_seed(1)
+    clean = randomize_bn_buffers(PreActResNet18(), 600).eval()
+    torch.manual_seed(2)
+    netg = UnetGenerator(Opt())
+    torch.manual_seed(3)
+    netf = randomize_bn_buffers(FrequencyModel(num_classes=2, n_input=3, input_size=32), 700).eval()
+    out["seeds"], out["bn_seeds"] = np.array([0, 1, 2, 3]), np.array([500, 600, 0, 700])
+    sigmas = [0.3, 0.85]
+    out["sigma"] = np.array(sigmas)
+    netc.eval()
+    netg.eval()
+    keys = ("clean_n", "clean_correct", "bd_n", "bd_correct", "bd_ba", "f_correct", "clean_model_correct",
+            "clean_model_bd_ba", "clean_model_bd_asr")
+    tr = {k: [] for k in keys}
+    for s, b in enumerate((64, 37)):
+        x = synth_images(b, 32, 8100 + s)
+        t = torch.randint(0, 10, (b,), generator=rng(8200 + s))
+        with torch.no_grad():
+            pc = netc(x)
+            ntrg = (t != 0).nonzero()[:, 0]
+            xc, tc = x[ntrg], t[ntrg]
+            ibd = _blur(torch.clamp(xc + _low_freq(netg(xc)) * 0.08, -1, 1), sigmas[s])
+            tbd = torch.zeros_like(tc)
+            pb = netc(ibd)
+            pf = netf(ref_dct.dct_2d(((ibd + 1) / 2 * 255).byte()))
+            cm_c, cm_b = clean(x), clean(ibd)
+        vals = (b, int((pc.argmax(1) == t).sum()), len(ntrg), int((pb.argmax(1) == tbd).sum()), int((pb.argmax(1) == tc).sum()),
+                int((pf.argmax(1) == 1).sum()), int((cm_c.argmax(1) == t).sum()), int((cm_b.argmax(1) == tc).sum()),
+                int((cm_b.argmax(1) == tbd).sum()))
+        for k, v in zip(keys, vals):
+            tr[k].append(v)
+        out["eval%d/logits_clean" % s] = pc.numpy()
+        out["eval%d/logits_bd" % s] = pb.numpy()
+    for k in keys:
+        out["eval/" + k] = np.array(tr[k])
+    out["eval/batch"], out["eval/seeds"] = np.array([64, 37]), np.array([8100, 8200])
+    # ---- victim step (frozen generator) then clean-classifier step, same netC, torch.optim.SGD
+    opt_c = torch.optim.SGD(netc.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    for p in netg.parameters():
+        p.requires_grad_(False)
+    ce = torch.nn.CrossEntropyLoss()
+    b = 48
+    x = synth_images(b, 32, 8300)
+    t = torch.randint(0, 10, (b,), generator=rng(8301))
+    t[:6] = 0
+    poisoned = torch.zeros(b, dtype=torch.bool)
+    poisoned[[0, 2, 5]] = True                       # a subset of the target-class images (dataloader_cleanbd.py:142-150)
+    out["victim/poisoned"], out["victim/sigma"], out["victim/seeds"] = poisoned.numpy(), np.float64(0.55), np.array([8300, 8301])
+    import copy
+    netc0 = copy.deepcopy(netc)       # both steps start from the same state (a second step from the first one's
+    #                                   result would mostly measure how ill-conditioned this random network is)
+    for tag, pz in (("victim", poisoned), ("cleanclf", torch.zeros(b, dtype=torch.bool))):
+        if tag == "cleanclf":
+            netc = netc0
+            opt_c = torch.optim.SGD(netc.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+        netc.train()
+        opt_c.zero_grad()
+        trg, ntrg = pz.nonzero()[:, 0], (~pz).nonzero()[:, 0]
+        xc = x[trg]
+        noise = netg(xc)
+        if len(trg):
+            noise = _low_freq(noise)
+        ibd = torch.clamp(xc + noise * 0.08, -1, 1)
+        if len(trg):
+            ibd = _blur(ibd, 0.55)
+        tot_in = torch.cat([ibd, x[ntrg]], 0)
+        tot_t = torch.cat([torch.zeros_like(t)[trg], t[ntrg]], 0)
+        preds = netc(tot_in)
+        loss = ce(preds, tot_t)
+        loss.backward()
+        out[tag + "/loss"] = np.float64(loss)
+        out[tag + "/correct"] = np.int64((preds.argmax(1) == tot_t).sum())
+        out[tag + "/gnorm"] = np.float64(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in netc.parameters())))
+        summarize([(k, p.grad) for k, p in netc.named_parameters()], out, tag + "/gp")
+        opt_c.step()
+        summarize(netc.state_dict().items(), out, tag + "/after")
+    save("eval_victim.npz", out)
 
 
 def golden_config():
@@ -325,10 +498,19 @@ def golden_config():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    only = sys.argv[1:]
+    if only:     # python tests/golden/make_golden.py golden_step_b128 golden_trajectory
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     golden_dct()
     golden_unet()
     golden_preact()
     golden_resnet()
     golden_freq()
     golden_step()
+    golden_step_b128()
+    golden_trajectory()
+    golden_trajectory_lr2e3()
+    golden_eval_victim()
     golden_config()

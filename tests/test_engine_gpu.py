@@ -344,24 +344,43 @@ def _oracle_state(m):
     return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
 
-@pytest.mark.parametrize("with_aug", [False, True])
-def test_alternated_step_vs_oracle(mods, golden, with_aug):
+def bench_batch(i, bs=128, rank=0, n_batches=8):
+    """Batch i of bench.py's synthetic pool (same generator walk as bench.py::synth_batches and
+    tests/golden/make_golden.py::bench_batch)."""
+    gen = torch.Generator().manual_seed(1234 + rank)
+    out = None
+    for _ in range(i % n_batches + 1):
+        u8 = torch.randint(0, 256, (bs, 3, 32, 32), generator=gen, dtype=torch.uint8)
+        t = torch.randint(0, 10, (bs,), generator=gen)
+        out = (((u8.float() / 255) - 0.5) / 0.5, t)
+    return out
+
+
+@pytest.mark.parametrize("with_aug,b", [(False, 16), (True, 16), (False, 128), (True, 128)])
+def test_alternated_step_vs_oracle(mods, golden, with_aug, b):
     """One alternated step on the GPU against the CPU oracle with bf16-emulating networks.
 
     Phase C is compared from the identical start state.  Phase G is compared from the engine's
     own post-Phase-C state (netC's update already differs between two bf16 realisations by the
     mask-flip noise described in the module docstring, and eval-mode BN with day-one running
-    statistics amplifies that), with the generator emulation teacher-forced."""
+    statistics amplifies that), with the generator emulation teacher-forced.
+
+    b = 128 is the benchmarked per-GPU batch (bench.py's own first batch and network seeds): DMA-tile
+    thresholds, split reductions, XCD orders, the statistics stage-1 launch and the 128-workgroup weight
+    gradients all take other branches there than at b = 16."""
     from oracle import combat_oracle as O
     from combat_amd.augment import params_from_oracle_struct
-    g = golden("step")
+    g = golden("step" if b == 16 else "step_b128")
     step_mod, nets = mods["step"], mods["nets"]
     seeds = [int(s) for s in g["seeds"]]
     netc, clean, netg, netf = _build(mods, seeds)
     oc, ok, og, of = (_oracle_state(m) for m in (netc, clean, netg, netf))
     old_c, old_g = _oracle_state(netc), _oracle_state(netg)
-    b = 16
-    x, t = T(g["step0/inputs"]), T(g["step0/targets"])
+    if b == 16:
+        x, t = T(g["step0/inputs"]), T(g["step0/targets"])
+    else:
+        x, t = bench_batch(0)
+        assert abs(float(x.double().sum()) - float(g["step0/x_sum"])) < 1e-6 and torch.equal(t, T(g["step0/targets"]))
     rng = np.random.default_rng(3)
     augs_o, augs_k = [None] * 5, [None] * 5
     if with_aug:
@@ -442,6 +461,142 @@ def test_alternated_step_vs_oracle(mods, golden, with_aug):
         exp = old_g[k] - 1e-2 * 1.9 * (gk + 5e-4 * old_g[k])
         assert rel_l2(netg.state_dict()[k].detach().cpu(), exp) < 1e-6, k
 
+    if not with_aug:
+        # ---------------- the HIP step against the fp32 trace recorded from the REFERENCE modules (first step;
+        # Phase G there starts from the reference's own fp32 Phase-C update, so this also bounds how far the
+        # bf16 realisation of one netC update moves the Phase-G losses): 2e-2 * max(1, |ref|), loss_l2 2 % rel.
+        for ours, key in (("loss_c_sum", "loss_c"), ("loss_ce_sum", "loss_ce"), ("clean_model_loss_sum", "clean_model_loss")):
+            r = float(g["trace/" + key][0])
+            assert abs(m[ours] - r) < 2e-2 * max(1.0, abs(r)), (key, m[ours], r)
+        r = float(g["trace/loss_l2"][0])
+        assert abs(m["loss_l2_sum"] - r) < 2e-2 * r, (m["loss_l2_sum"], r)
+        for ours, key in (("clean_model_correct", "clean_model_correct"), ("clean_model_bd_ba", "clean_model_bd_ba"),
+                          ("clean_model_bd_asr", "clean_model_bd_asr"), ("f_correct", "f_correct")):
+            assert abs(m[ours] - float(g["trace/" + key][0])) <= max(2, 0.03 * b), (key, m[ours], float(g["trace/" + key][0]))
+
+
+def test_backward_plans_do_not_share_weight_gradient_scratch(mods):
+    """the last weight gradient of a backward plan runs on the plan's own stream while the
+    previous ones may still be writing / reducing their partial-sum slabs on the auxiliary stream; they used
+    to share one scratch base.  At N = 128 (where every 3x3 weight gradient takes the slab path) the
+    multi-stream backward must give, per tensor, what the in-line (one stream) replay gives."""
+    nets, ops, engine = mods["nets"], mods["ops"], mods["engine"]
+    gen = torch.Generator().manual_seed(4)
+    x = torch.rand(128, 3, 32, 32, generator=gen) * 2 - 1
+    t = torch.randint(0, 10, (128,), generator=gen)
+    # ---- classifier: stem.wgrad is the aux=False launch
+    m = seeded(nets.PreActResNet18, 0).cuda()
+    eng = m._net_engine()
+    eng.refresh()
+    slot = eng.slot("race", 128, 32)
+    ops.image_to_c8(x.cuda(), eng.input(slot))
+    eng.head_bufs(slot)["targets"].copy_(t.cuda())
+    eng.forward_plan(slot, True).run()
+    bwd = eng.backward_train_plan(slot)
+    names = [k for k, _ in m.named_parameters()]
+
+    def grads(fp, names, run):
+        run()
+        torch.cuda.synchronize()
+        return {k: fp.logical(fp.grad, k).detach().float().cpu().clone() for k in names}
+
+    engine.Plan.serial = True
+    try:
+        ref = grads(eng.fp, names, bwd.run)
+    finally:
+        engine.Plan.serial = False
+    for rep in range(4):
+        got = grads(eng.fp, names, bwd.run)
+        for k in names:
+            assert rel_l2(got[k], ref[k]) < 1e-5, ("preact", rep, k, rel_l2(got[k], ref[k]))
+    # ---- generator: conv0_0.wgrad is the aux=False launch
+    gm = seeded(lambda: nets.UnetGenerator(None), 2).cuda()
+    eg = gm._net_engine()
+    eg.refresh()
+    sg = eg.slot("race", 128, 32)
+    ops.image_to_c8(x.cuda(), eg.input(sg))
+    eg.forward_plan(sg).run()
+    z = sg.buf("g.z", (128, 32, 32, 8))
+    z.zero_()
+    z[..., :3] = (torch.randn(128, 32, 32, 3, generator=gen) * 1e-2).to(bf16).cuda()
+    gb = eg.backward_plan(sg)
+    gnames = [k for k, _ in gm.named_parameters()]
+    engine.Plan.serial = True
+    try:
+        ref = grads(eg.fp, gnames, gb.run)
+    finally:
+        engine.Plan.serial = False
+    for rep in range(4):
+        got = grads(eg.fp, gnames, gb.run)
+        for k in gnames:
+            assert rel_l2(got[k], ref[k]) < 1e-5 or float(ref[k].abs().max()) == 0.0, ("unet", rep, k, rel_l2(got[k], ref[k]))
+
+
+def _ema(v, a=0.1):
+    out, m = [], float(v[0])
+    for x in v:
+        m = (1 - a) * m + a * float(x)
+        out.append(m)
+    return np.array(out)
+
+
+@pytest.mark.parametrize("name,steps", [("trajectory_lr2e3", 100), ("trajectory", 40)])
+def test_trajectory_vs_reference_trace(mods, golden, name, steps):
+    """SURVEY 8(d) / north_star "loss curves must match": alternated steps at B = 32 over a pool of 25 fixed
+    synthetic batches (augmentation off, recorded num_bd / sigma per step) against the trace the REFERENCE's
+    own modules + torch.optim.SGD produced in fp32 (tests/golden/make_golden.py::golden_trajectory*).
+
+    `trajectory_lr2e3` (--lr_C 2e-3 --lr_G 2e-3), 100 steps: exponential moving averages (alpha 0.1) of loss_c,
+    clean_model_loss and loss_l2 within 2 % of the reference's at EVERY step; loss_ce -- whose raw curve
+    alternates between ~0 and ~2 with the recorded blur sigma of the step -- within 2 % + 0.02; per-step
+    counters within 4 images of 32 and their 100-step totals within 1.5 %.  (The fp32 oracle driven with the
+    CPU bf16 emulation, the idealised form of this design, measures 0.23 % / 0 % / 0.14 % and 7 % on loss_ce's
+    EMA at step 99 = 0.05 absolute.)
+    `trajectory` (the default lr 1e-2): the reference's own run turns chaotic after ~45 steps on these
+    random-label batches (loss_ce jumps between 0 and 50-290), so only its smooth first 40 steps are compared:
+    loss_c / clean_model_loss / loss_l2 EMAs within 5 %, loss_ce within 5 % + 0.03."""
+    step_mod = mods["step"]
+    g = golden(name)
+    seeds = [int(s) for s in g["seeds"]]
+    netc, clean, netg, netf = _build(mods, seeds)
+    opt = Opt()
+    st = step_mod.AlternatedStep(netc.cuda(), netg.cuda(), clean.cuda().eval(), netf.cuda().eval(), opt)
+    b, pool_n, lr = 32, int(g["pool"]), float(g["lr"])
+    s_img, s_lab = (int(v) for v in g["pool_seeds"])
+
+    def synth(i):
+        u8 = torch.randint(0, 256, (b, 3, 32, 32), generator=torch.Generator().manual_seed(s_img + i), dtype=torch.uint8)
+        return (u8.float() / 255 - 0.5) / 0.5, torch.randint(0, 10, (b,), generator=torch.Generator().manual_seed(s_lab + i))
+
+    pool = [synth(i) for i in range(pool_n)]
+    keys = (("loss_c_sum", "loss_c"), ("loss_ce_sum", "loss_ce"), ("clean_model_loss_sum", "clean_model_loss"),
+            ("loss_l2_sum", "loss_l2"), ("clean_correct", "clean_correct"), ("bd_correct", "bd_correct"),
+            ("clean_model_correct", "clean_model_correct"), ("clean_model_bd_ba", "clean_model_bd_ba"),
+            ("clean_model_bd_asr", "clean_model_bd_asr"), ("train_correct", "train_correct"))
+    ours = {k: [] for _, k in keys}
+    for s in range(steps):
+        x, t = pool[s % pool_n]
+        st.reset_metrics()
+        st.run(x.cuda(), t, step_mod.StepRandomness(int(g["num_bd"][s]), float(g["sigma_c"][s]), float(g["sigma_g"][s]),
+                                                    [None] * 5), lr_c=lr, lr_g=lr)
+        m = st.read_metrics()
+        for mk, k in keys:
+            ours[k].append(m[mk])
+    tight = name == "trajectory_lr2e3"
+    rel = 0.02 if tight else 0.05
+    report = {}
+    for k, floor in (("loss_c", 0.0), ("clean_model_loss", 0.0), ("loss_l2", 0.0), ("loss_ce", 0.02 if tight else 0.03)):
+        e_o, e_r = _ema(ours[k]), _ema(g["trace/" + k][:steps])
+        dev = np.abs(e_o - e_r) - floor
+        worst = int(np.argmax(dev / np.maximum(np.abs(e_r), 1e-9)))
+        report[k] = (float((dev / np.maximum(np.abs(e_r), 1e-9)).max()), worst)
+        assert np.all(dev <= rel * np.abs(e_r)), (name, k, report[k], e_o[worst], e_r[worst])
+    print(name, "max relative EMA deviations (value, step):", report)
+    for k in ("clean_correct", "bd_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr", "train_correct"):
+        o, r = np.array(ours[k], dtype=np.float64), g["trace/" + k][:steps]
+        assert np.abs(o - r).max() <= 4, (name, k, int(np.abs(o - r).argmax()), np.abs(o - r).max())
+        assert abs(o.sum() - r.sum()) <= max(0.015 * steps * b, 8), (name, k, o.sum(), r.sum())
+
 
 def test_alternated_step_celeba_shape_resnet18(mods):
     """BASELINE config 4's shape (CelebA: 3 x 64 x 64, 8 classes, ResNet18 surrogate and clean model, UNet at
@@ -517,3 +672,169 @@ def test_alternated_step_runs_with_sampled_randomness_and_empty_poison(mods):
     assert all(np.isfinite(v) for v in m.values())
     for p in list(netc.parameters()) + list(netg.parameters()):
         assert torch.isfinite(p).all()
+
+
+def test_classifier_step_metrics_cover_ragged_batches(mods):
+    """CIFAR-10's last batch is ragged (50000 % 128 = 80); ClassifierStep keeps a slot,
+    plans and loss / accuracy cells per batch size, and read_metrics sums (and resets) all of them."""
+    step_mod, nets = mods["step"], mods["nets"]
+    opt = Opt()
+    gen = torch.Generator().manual_seed(8)
+    batches = [((torch.rand(n, 3, 32, 32, generator=gen) * 2 - 1), torch.randint(0, 10, (n,), generator=gen)) for n in (48, 48, 20, 48)]
+    totals = []
+    for per_batch in (False, True):
+        netc = seeded(nets.PreActResNet18, 0).cuda()
+        st = step_mod.ClassifierStep(netc, opt)
+        acc = {"loss_sum": 0.0, "correct": 0}
+        for x, t in batches:
+            st.run(x.cuda(), t)
+            if per_batch:
+                m = st.read_metrics(reset=True)
+                acc = {k: acc[k] + m[k] for k in acc}
+        if not per_batch:
+            acc = st.read_metrics(reset=True)
+            again = st.read_metrics()
+            assert again["loss_sum"] == 0.0 and again["correct"] == 0      # every slot was reset
+        totals.append(acc)
+    n_all = sum(x.shape[0] for x, _ in batches)
+    assert abs(totals[0]["loss_sum"] - totals[1]["loss_sum"]) < 1e-3 * totals[1]["loss_sum"], totals
+    assert totals[0]["correct"] == totals[1]["correct"] and 0 <= totals[0]["correct"] <= n_all
+    # the reference accumulates the batch-MEAN loss (train_victim.py:139): ~ln(10) per batch, over ALL four batches
+    assert 1.5 * len(batches) < totals[0]["loss_sum"] < 4.0 * len(batches)
+
+
+# ---------------------------------------------------------------- evaluation loops and the victim / clean-classifier step
+
+
+def _eval_victim_nets(g, mods):
+    """The networks of tests/golden/eval_victim.npz: seeds + seeded BatchNorm running statistics."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_oracle_golden as TO
+    return TO.eval_victim_nets(g), TO
+
+
+def test_eval_loops_vs_reference_counters(mods, golden, tmp_path, monkeypatch):
+    """SURVEY 8(a)-E / (f)1: `eval.py::eval` (reference eval.py:108-152) and the in-training
+    `train_generator.py::eval` (reference :321-465) on a 101-image synthetic test set (batches of 64 and 37, as
+    recorded) with the recorded blur sigmas, against (1) the counters the REFERENCE modules produced
+    (tests/golden/eval_victim.npz) and (2) the oracle's eval_batch driven with the bf16 emulation.  Counters are
+    integer argmax counts over 101 / ~90 images of freshly initialised networks (small logit margins): +-3 images
+    against fp32, +-2 against the emulation."""
+    import importlib
+    from oracle import combat_oracle as O
+    from combat_amd import trigger
+    from combat_amd.data import ArrayLoader
+    from combat_amd.dist import NullWriter
+    g = golden("eval_victim")
+    (netc, clean, netg, netf), TO = _eval_victim_nets(g, mods)
+    sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+    oc, ok, og, of = sd(netc), sd(clean), sd(netg), sd(netf)
+    s_img, s_lab = (int(v) for v in g["eval/seeds"])
+    u8, lab = [], []
+    for s, b in enumerate(int(v) for v in g["eval/batch"]):
+        u8.append(torch.randint(0, 256, (b, 3, 32, 32), generator=torch.Generator().manual_seed(s_img + s), dtype=torch.uint8))
+        lab.append(torch.randint(0, 10, (b,), generator=torch.Generator().manual_seed(s_lab + s)))
+    test_dl = ArrayLoader(torch.cat(u8).numpy(), torch.cat(lab).numpy(), 64, False)
+    sig = [float(v) for v in g["sigma"]]
+    # oracle with the bf16 emulation on the same batches
+    emu = {}
+    for s, (xb, tb) in enumerate(test_dl):
+        r = O.eval_batch(oc, og, xb, tb, sig[s], O.StepConfig(), clean=ok, netf=of, clf_fn=E.preact_forward_emu,
+                         gen_fn=E.unet_forward_emu)
+        emu = {k: emu.get(k, 0) + v for k, v in r.items()}
+    ref = {k[5:]: int(g[k].sum()) for k in g if k.startswith("eval/") and k not in ("eval/batch", "eval/seeds")}
+    assert ref["clean_n"] == 101 and emu["clean_n"] == 101
+
+    class EOpt(Opt):
+        device = "cuda"
+        ckpt_path = str(tmp_path / "ck.pth.tar")
+
+    opt = EOpt()
+    netc, clean, netg, netf = netc.cuda().eval(), clean.cuda().eval(), netg.cuda().eval(), netf.cuda().eval()
+    draws = []
+    monkeypatch.setattr(trigger, "sample_sigma", lambda rng=(0.1, 1.0): draws.pop(0))
+
+    def near(ours, key, n_key):
+        n = ref[n_key]
+        assert abs(ours * n / 100.0 - ref[key]) <= 3.01, (key, ours * n / 100.0, ref[key])
+        assert abs(ours * n / 100.0 - emu[key]) <= 2.01, (key, ours * n / 100.0, emu[key])
+
+    # ---- eval.py (reference eval.py:108-152): clean accuracy, Bd BA, Bd ASR
+    ev = importlib.import_module("eval")
+    draws[:] = list(sig)
+    acc_clean, acc_ba, acc_asr = ev.eval(netc, netg, test_dl, NullWriter(), opt)
+    near(acc_clean, "clean_correct", "clean_n")
+    near(acc_ba, "bd_ba", "bd_n")
+    near(acc_asr, "bd_correct", "bd_n")
+    # ---- train_generator.py::eval (reference :321-465): six accuracies + the checkpoint
+    tg = importlib.import_module("train_generator")
+    oC = torch.optim.SGD(netc.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    oG = torch.optim.SGD(netg.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    sC = torch.optim.lr_scheduler.MultiStepLR(oC, [100, 150], 0.1)
+    sG = torch.optim.lr_scheduler.MultiStepLR(oG, [100, 150], 0.1)
+    draws[:] = list(sig)
+    best = tg.eval(netc, oC, sC, netg, oG, sG, netf, clean, test_dl, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, NullWriter(), 0, opt)
+    for ours, key, n_key in zip(best, ("clean_correct", "bd_correct", "f_correct", "clean_model_correct", "clean_model_bd_ba",
+                                       "clean_model_bd_asr"), ("clean_n", "bd_n", "bd_n", "clean_n", "bd_n", "bd_n")):
+        near(ours, key, n_key)
+    ck = torch.load(opt.ckpt_path, map_location="cpu", weights_only=True)
+    assert abs(ck["best_clean_acc"] - best[0]) < 1e-9 and len(ck["netC"]) == 102
+
+
+def test_victim_and_clean_classifier_step_vs_oracle(mods, golden, monkeypatch):
+    """ClassifierStep = the loop bodies of train_victim.py:102-141 (frozen generator poisons the
+    flagged images; D3 intent) and train_clean_classifier.py:87-110, against the trace of the REFERENCE modules
+    (tests/golden/eval_victim.npz: loss within 1e-2, accuracy count +-2, gradient norm within 3 %, parameter update
+    within the mask-flip bound 0.35) and, teacher-forced, against the oracle's victim_step driven with the bf16
+    emulation (gradients rel-L2 <= 4e-2: pins batch order, labels, trigger and backward wiring)."""
+    from oracle import combat_oracle as O
+    from combat_amd import trigger
+    step_mod = mods["step"]
+    g = golden("eval_victim")
+    vi, vl = (int(v) for v in g["victim/seeds"])
+    u8 = torch.randint(0, 256, (48, 3, 32, 32), generator=torch.Generator().manual_seed(vi), dtype=torch.uint8)
+    x = (u8.float() / 255 - 0.5) / 0.5
+    t = torch.randint(0, 10, (48,), generator=torch.Generator().manual_seed(vl))
+    t[:6] = 0
+    sigma = float(g["victim/sigma"])
+    monkeypatch.setattr(trigger, "sample_sigma", lambda rng=(0.1, 1.0): sigma)
+    for tag, pz in (("victim", torch.from_numpy(g["victim/poisoned"])), ("cleanclf", None)):
+        (netc, clean, netg, netf), TO = _eval_victim_nets(g, mods)
+        sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+        oc, og = sd(netc), sd(netg)
+        p0 = {k: v.detach().clone() for k, v in netc.named_parameters()}
+        names = [k for k, _ in netc.named_parameters()]
+        netc, netg = netc.cuda(), netg.cuda().eval()
+        opt = Opt()
+        st = step_mod.ClassifierStep(netc, opt, netg if pz is not None else None)
+        st.run(x.cuda(), t, pz)
+        torch.cuda.synchronize()
+        m = st.read_metrics()
+        assert abs(m["loss_sum"] - float(g[tag + "/loss"])) < 1e-2, (tag, m["loss_sum"], float(g[tag + "/loss"]))
+        assert abs(m["correct"] - int(g[tag + "/correct"])) <= 2
+        fp = st.eC.fp
+        gn = float(fp.grad.double().norm())
+        assert abs(gn - float(g[tag + "/gnorm"])) < 3e-2 * float(g[tag + "/gnorm"]), (tag, gn, float(g[tag + "/gnorm"]))
+        # teacher-forced emulation through the oracle's victim_step
+        keys = ["stem"] + ["b%d.%s" % (b, s) for b in range(8) for s in ("y1", "out", "sc")]
+        force = stored(st.slot, keys)
+        clf = lambda p, xx, train: E.preact_forward_emu(p, xx, train, force=force)
+        r = O.victim_step(oc, [None] * len(names), x, t, O.StepConfig(), netg=og if pz is not None else None, poisoned=pz,
+                          sigma=sigma, clf_fn=clf, gen_fn=E.unet_forward_emu)
+        ours = flat_grads(fp, names)
+        e_tf = rel_l2(ours, torch.cat([a.reshape(-1) for a in r["grads"]]))
+        assert e_tf < 4e-2, (tag, e_tf)
+        assert abs(m["loss_sum"] - r["loss"]) < 5e-3 and abs(m["correct"] - r["correct"]) <= 1
+        # the optimiser applied the engine's own gradient; the update stays within the mask-flip bound of fp32's
+        num = den = 0.0
+        for k in names:
+            ref_after_idx, ref_after = g["%s/after/%s/idx" % (tag, k)], g["%s/after/%s/val" % (tag, k)]
+            d_ref = ref_after - p0[k].double().flatten()[ref_after_idx].numpy()
+            d_our = (dict(netc.named_parameters())[k].detach().cpu().double().flatten()[ref_after_idx] -
+                     p0[k].double().flatten()[ref_after_idx]).numpy()
+            num, den = num + float(((d_our - d_ref) ** 2).sum()), den + float((d_ref ** 2).sum())
+        assert (num / den) ** 0.5 < 0.35, (tag, (num / den) ** 0.5)
+        for k in ("conv1.weight", "layer3.0.shortcut.0.weight", "linear.bias"):
+            gk = fp.logical(fp.grad, k).cpu()
+            exp = p0[k] - 1e-2 * 1.9 * (gk + 5e-4 * p0[k])
+            assert rel_l2(dict(netc.named_parameters())[k].detach().cpu(), exp) < 1e-6, k

@@ -296,6 +296,38 @@ def test_data_loader_normalisation_sharding_and_poison_flags():
         get_dataloader(O2(), True)
 
 
+def test_array_loader_shards_are_disjoint_equal_and_rng_independent():
+    """data-parallel shards of an epoch are disjoint parts of ONE permutation that depends
+    only on (base_seed, epoch) -- not on what a rank drew from its global generators meanwhile -- and every
+    rank walks the same number of batches (a rank one step ahead would hang in the gradient all-reduce)."""
+    from combat_amd.data import ArrayLoader
+    x = np.zeros((203, 3, 4, 4), np.uint8)      # 203 = 3 * 67 + 2: ragged over 3 ranks
+    loaders = [ArrayLoader(x, np.arange(203), 16, True, rank=r, world=3, base_seed=11) for r in range(3)]
+    assert len({len(l) for l in loaders}) == 1 and len(loaders[0]) == 5          # ceil(68 / 16) on every rank
+    for epoch in range(3):
+        ids = []
+        for r, l in enumerate(loaders):
+            torch.manual_seed(1000 * r + epoch)           # ranks diverge in their global generator ...
+            torch.rand(r + 1)
+            got = torch.cat([b[1] for b in l])
+            assert len(got) == 68
+            ids.append(got)
+        allids = torch.cat(ids).tolist()
+        assert set(allids) == set(range(203)) and len(allids) == 204              # one wrapped sample pads the epoch
+        assert torch.equal(ids[0], loaders[0].epoch_order(epoch))                  # ... and the shards do not care
+    a, b2 = loaders[0].epoch_order(0), loaders[0].epoch_order(1)
+    assert not torch.equal(a, b2)
+    # evaluation loaders: exact (possibly uneven) strided shards, nothing counted twice
+    ev = [ArrayLoader(x, np.arange(203), 16, False, rank=r, world=3) for r in range(3)]
+    got = torch.cat([torch.cat([b[1] for b in l]) for l in ev])
+    assert sorted(got.tolist()) == list(range(203))
+    # unseeded construction draws the base seed from the global generator (DataLoader's RandomSampler does)
+    torch.manual_seed(5)
+    s1 = ArrayLoader(x, np.arange(203), 16, True).base_seed
+    torch.manual_seed(5)
+    assert ArrayLoader(x, np.arange(203), 16, True).base_seed == s1
+
+
 def test_progress_bar_and_scalar_writer(tmp_path, capsys):
     from combat_amd.log import SummaryWriter, progress_bar
     progress_bar(0, 3, "Clean Acc: 10.0000")
@@ -363,11 +395,14 @@ def _dp_worker(rank, world, port, tmp):
     ok = ok and torch.equal(gathered[0], gathered[1])                 # replicas stay identical
     counts = cdist.all_reduce_counters([rank + 1, 10])
     ok = ok and counts == [3.0, 20.0]
-    torch.manual_seed(1)
-    ids = torch.cat([b[1] for b in ArrayLoader(np.zeros((50, 3, 4, 4), np.uint8), np.arange(50), 8, True, rank=rank, world=world)])
-    allids = [torch.zeros(25, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(allids, ids)
-    ok = ok and sorted(torch.cat(allids).tolist()) == list(range(50))  # disjoint, complete epoch shards
+    torch.manual_seed(1 + 17 * rank)     # unseeded ranks: the loader's base seed is rank 0's draw, broadcast
+    dl = ArrayLoader(np.zeros((51, 3, 4, 4), np.uint8), np.arange(51), 8, True, rank=rank, world=world)
+    for epoch in range(2):
+        ids = torch.cat([b[1] for b in dl])
+        allids = [torch.zeros(26, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allids, ids)
+        ok = ok and len(ids) == 26 and len(dl) == 4
+        ok = ok and set(torch.cat(allids).tolist()) == set(range(51))   # disjoint (one wrapped sample), complete epoch shards
     open(os.path.join(tmp, "ok%d" % rank), "w").write(str(bool(ok)))
     dist.destroy_process_group()
 

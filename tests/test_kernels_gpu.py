@@ -579,6 +579,70 @@ def test_wgrad3x3_dma_kernel(ops, n, hw, c, k):
         assert rel_l2(dw, ref) < 2e-3, (split, ws)
 
 
+# ---- the benchmarked shape: every convolution of PreActResNet18 (classifier_models/preact_resnet.py:21,23,27-29,77)
+# and of the UnetGenerator (networks/models.py:275-314) at the metric's per-GPU batch N = 128.  At this size the
+# dispatcher takes branches the small cases above never reach (DMA-tile thresholds on the workgroup count,
+# split reductions below 96 tiles, channel-tile-fastest / pixel-tile-fastest XCD order, 128-workgroup weight-
+# gradient sizing with slab workspaces) -- so forward, input gradient and weight gradient are each checked here
+# with the AUTOMATIC tile against fp32 torch on the CPU, same bf16-rounded operands.
+B128_SHAPES = [
+    # hw, c, k, r, stride                         PreActResNet18
+    (32, 64, 64, 3, 1), (32, 64, 128, 3, 2), (32, 64, 128, 1, 2), (16, 128, 128, 3, 1), (16, 128, 256, 3, 2),
+    (16, 128, 256, 1, 2), (8, 256, 256, 3, 1), (8, 256, 512, 3, 2), (8, 256, 512, 1, 2), (4, 512, 512, 3, 1),
+    # UnetGenerator (shapes not already above)
+    (16, 64, 64, 3, 1), (16, 64, 128, 3, 2), (8, 128, 128, 3, 1), (8, 128, 256, 3, 2), (4, 256, 256, 3, 1),
+    (4, 256, 512, 3, 2), (2, 512, 512, 3, 1), (4, 512, 256, 3, 1), (8, 256, 128, 3, 1), (16, 128, 64, 3, 1),
+    # 3-channel ends: classifier stem / UNet conv0_0 (c8 hi/lo images) and the UNet output layer (K = 3 -> 8)
+    (32, 3, 64, 3, 1), (32, 3, 64, 3, 2), (32, 64, 3, 3, 1),
+]
+
+
+@pytest.mark.parametrize("hw,c,k,r,stride", B128_SHAPES)
+def test_conv_shapes_at_batch_128(ops, hw, c, k, r, stride):
+    n, pad = 128, (1 if r == 3 else 0)
+    c_pad = 8 if c == 3 else c
+    x = torch.randn(n, c, hw, hw, generator=g(700)) if c != 3 else torch.rand(n, 3, hw, hw, generator=g(700)) * 2 - 1
+    w, pc = make_conv(ops, k, c, r, stride, pad, 701, c_pad=c_pad, dup=(c == 3))
+    p, q = pc.out_hw(hw, hw)
+    kc = pc.Kc
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    if c == 3:
+        xin = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+        ops.image_to_c8(dev(x), xin)
+        x_seen = x                       # hi/lo split: the stem sees the un-rounded pixels (to ~16 bits)
+    else:
+        xin, x_seen = nhwc(x), rb(x)
+    # forward with the statistics epilogue (what a train-mode layer launches)
+    y = torch.empty(n, p, q, kc, dtype=bf16, device="cuda")
+    a = ops.conv_args(xin, y, pc, 0, stats_kind=1, workspace=ws)
+    rows, rpi = ops.conv_stats_layout(a)
+    stats = torch.zeros(rows, 2, kc, device="cuda")
+    a.stats = stats.data_ptr()
+    ops.conv_launch(a)
+    ref = F.conv2d(x_seen, rb(w), stride=stride, padding=pad)
+    yr = nchw(y)[:, :k]
+    assert rel_l2(yr, ref) < 4e-3
+    tot = stats.sum(0).cpu()
+    assert rel_l2(tot[0, :k], yr.sum((0, 2, 3))) < 1e-4 and rel_l2(tot[1, :k], (yr * yr).sum((0, 2, 3))) < 1e-4
+    # input gradient
+    dy = torch.randn(n, k, p, q, generator=g(702))
+    dy_d = torch.zeros(n, p, q, kc, dtype=bf16, device="cuda")
+    dy_d[..., :k] = nhwc(dy)
+    dx = torch.empty(n, hw, hw, c_pad, dtype=bf16, device="cuda")
+    ops.conv_launch(ops.conv_args(dy_d, dx, pc, 1, workspace=ws))
+    dx_ref = torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), stride=stride, padding=pad)
+    assert rel_l2(nchw(dx)[:, :c], dx_ref) < 4e-3
+    # weight gradient: atomics path and slab-workspace path (the engines pass a workspace)
+    dw_ref = torch.nn.grad.conv2d_weight(x_seen if c != 3 else rb(x), (k, c, r, r), rb(dy), stride=stride, padding=pad)
+    dw_ref = dw_ref.permute(0, 2, 3, 1).reshape(k, r * r, c)
+    if c == 3:
+        ops.image_to_c8(dev(rb(x)), xin)
+    for use_ws in (None, True):
+        dw = torch.zeros(k, r * r, c, device="cuda")
+        ops.conv_wgrad(xin, dy_d, pc, dw, workspace=use_ws)
+        assert rel_l2(dw, dw_ref) < 2e-3, use_ws
+
+
 @pytest.mark.parametrize("per_image,with_affine", [(False, True), (True, True), (False, False)])
 def test_affine_act_matches_the_conv_prologue(ops, per_image, with_affine):
     """combat_affine_act materialises what a convolution prologue computes: a prologue-free convolution of

@@ -235,3 +235,186 @@ def test_alternated_step_trace(golden):
             assert out[k] == int(g["trace/" + k][s]), (s, k)
     check_summary(g, "final/netc", netc.items(), rtol=5e-3, atol=4e-4)
     check_summary(g, "final/netg", netg.items(), rtol=5e-3, atol=4e-4)
+
+
+# ---------------------------------------------------------------- the bf16 emulation is pinned to the oracle
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def test_bf16_emulation_without_rounding_is_the_oracle():
+    """tests/bf16_emu.py is the tight reference of the GPU engine tests.  With its rounding switched off it
+    must reproduce the (golden-pinned) oracle forwards AND their autograd gradients: same dataflow, same
+    statistics, same running-stat updates.  Run in float64 so that what is compared is the dataflow and not
+    fp32 re-association (the emulation applies BatchNorm as x*scale+shift, drops the conv biases that an
+    InstanceNorm cancels and, for the eval-mode ResNet18, folds bn2 / the shortcut norm into the weights, as
+    the engine does): rel-L2 <= 1e-9 everywhere (VERDICT r1 asked for <= 1e-6)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import bf16_emu as E
+    from combat_amd import nets
+    from oracle import combat_oracle as O
+    gen = torch.Generator().manual_seed(77)
+    f64 = torch.float64
+    dbl = lambda sd: {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    E.ROUND = False
+    try:
+        # ---- UNet
+        torch.manual_seed(3)
+        sd = dbl(nets.UnetGenerator(None).state_dict())
+        names = O.trainable_names(sd)
+        x = torch.rand(3, 3, 32, 32, generator=gen, dtype=f64) * 2 - 1
+        cot = torch.randn(3, 3, 32, 32, generator=gen, dtype=f64)
+        outs = []
+        for fn in (O.unet_forward, E.unet_forward_emu):
+            p = {k: v.clone().requires_grad_(k in names) for k, v in sd.items()}
+            xi = x.clone().requires_grad_(True)
+            y = fn(p, xi)
+            g = torch.autograd.grad(y, [xi] + [p[k] for k in names], cot, allow_unused=True)
+            outs.append((y.detach(), [torch.zeros_like(t) if a is None else a for t, a in zip([xi] + [p[k] for k in names], g)]))
+        assert _rel(outs[1][0], outs[0][0]) < 1e-9
+        for k, a, b in zip(["x"] + names, outs[1][1], outs[0][1]):
+            if k.endswith(".bias") and k not in ("upconv0_0.bias", "conv0_0.bias"):
+                # a bias in front of an InstanceNorm: the emulation does not add it (exact zero gradient); the
+                # oracle's gradient for it is zero up to rounding
+                assert float(a.abs().max()) == 0.0 and float(b.abs().max()) < 1e-9, k
+                continue
+            assert _rel(a, b) < 1e-9, (k, _rel(a, b))
+        # ---- classifiers, train then eval (running statistics carried over)
+        cases = ((nets.PreActResNet18, O.preact_resnet18_forward, E.preact_forward_emu, 32, 10),
+                 (lambda: nets.ResNet18(num_classes=8, input_size=64), O.resnet18_forward, E.resnet_forward_emu, 64, 8))
+        for ctor, f_o, f_e, hw, classes in cases:
+            torch.manual_seed(5)
+            sd = dbl(ctor().state_dict())
+            names = O.trainable_names(sd)
+            x = torch.rand(4, 3, hw, hw, generator=gen, dtype=f64) * 2 - 1
+            t = torch.randint(0, classes, (4,), generator=gen)
+            states = []
+            for fn in (f_o, f_e):
+                p = {k: v.clone() for k, v in sd.items()}
+                for k in names:
+                    p[k].requires_grad_(True)
+                res = []
+                for train in (True, False):
+                    xi = x.clone().requires_grad_(True)
+                    lg = fn(p, xi, train)
+                    g = torch.autograd.grad(torch.nn.functional.cross_entropy(lg, t), [xi] + [p[k] for k in names])
+                    res.append((lg.detach(), g))
+                states.append((res, {k: v.detach().clone() for k, v in p.items() if "running" in k or "num_batches" in k}))
+            (ro, bo), (re_, be) = states
+            for mode in (0, 1):
+                assert _rel(re_[mode][0], ro[mode][0]) < 1e-9, (hw, mode)
+                for k, a, b in zip(["x"] + names, re_[mode][1], ro[mode][1]):
+                    assert _rel(a, b) < 1e-9 or float(b.abs().max()) < 1e-12, (hw, mode, k, _rel(a, b))
+            for k in bo:
+                assert _rel(be[k].double(), bo[k].double()) < 1e-9, k
+    finally:
+        E.ROUND = True
+
+
+def test_batched_augmentation_equals_the_per_sample_loop():
+    """oracle.post_tensor_transform_batched (used when the oracle step is timed on a device as the stock
+    PyTorch baseline) is the same differentiable map as the per-sample restatement."""
+    import numpy as np
+    from oracle import combat_oracle as O
+    rng = np.random.default_rng(5)
+    b = 12
+    p = O.AugParams(rng.integers(0, 11, b).astype(np.int32), rng.integers(0, 11, b).astype(np.int32),
+                    np.where(rng.random(b) < 0.5, rng.uniform(-10, 10, b), 0).astype(np.float32),
+                    (rng.random(b) < 0.5).astype(np.int32))
+    x = torch.rand(b, 3, 32, 32, generator=torch.Generator().manual_seed(1)) * 2 - 1
+    cot = torch.randn(b, 3, 32, 32, generator=torch.Generator().manual_seed(2))
+    outs = []
+    for fn in (O.post_tensor_transform, O.post_tensor_transform_batched):
+        xi = x.clone().requires_grad_(True)
+        y = fn(xi, p)
+        (gx,) = torch.autograd.grad(y, xi, cot)
+        outs.append((y.detach(), gx))
+    # (the loop evaluates cos/sin of the angle in double, the batched form in fp32: ~3e-6 on values in [-1, 1])
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-5
+    assert float((outs[0][1] - outs[1][1]).abs().max()) < 1e-4
+    assert O.post_tensor_transform_batched(x, None) is x
+
+
+# ---------------------------------------------------------------- evaluation loop body, victim / clean-classifier step
+
+
+def randomize_bn_buffers(net, seed):
+    """tests/golden/make_golden.py::randomize_bn_buffers on combat_amd's mirror modules (same module order)."""
+    i = 0
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.05, generator=torch.Generator().manual_seed(seed + i))
+                m.running_var.uniform_(0.6, 1.4, generator=torch.Generator().manual_seed(seed + 1000 + i))
+                i += 1
+    return net
+
+
+def eval_victim_nets(g):
+    from combat_amd import nets
+    seeds, bns = [int(v) for v in g["seeds"]], [int(v) for v in g["bn_seeds"]]
+    out = []
+    for ctor, sd, bn in zip((nets.PreActResNet18, nets.PreActResNet18, lambda: nets.UnetGenerator(None),
+                             lambda: nets.FrequencyModel(2, 3, 32)), seeds, bns):
+        torch.manual_seed(sd)
+        m = ctor()
+        out.append(randomize_bn_buffers(m, bn) if bn else m)
+    return out      # netc, clean, netg, netf
+
+
+def synth_images(b, hw, seed):
+    u8 = torch.randint(0, 256, (b, 3, hw, hw), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+    return (u8.float() / 255 - 0.5) / 0.5
+
+
+def test_eval_batch_and_victim_step_match_the_reference_modules(golden):
+    """oracle.eval_batch / oracle.victim_step against counters, losses and gradients recorded from the reference's
+    own modules in the order of train_generator.py:353-391 / eval.py:119-143 and train_victim.py:102-141 (D3
+    intent) / train_clean_classifier.py:87-110 (tests/golden/make_golden.py::golden_eval_victim)."""
+    from oracle import combat_oracle as O
+    g = golden("eval_victim")
+    netc, clean, netg, netf = eval_victim_nets(g)
+    sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+    oc, ok, og, of = sd(netc), sd(clean), sd(netg), sd(netf)
+    cfg = O.StepConfig()
+    s_img, s_lab = (int(v) for v in g["eval/seeds"])
+    for s, b in enumerate(int(v) for v in g["eval/batch"]):
+        x = synth_images(b, 32, s_img + s)
+        t = torch.randint(0, 10, (b,), generator=torch.Generator().manual_seed(s_lab + s))
+        r = O.eval_batch(oc, og, x, t, float(g["sigma"][s]), cfg, clean=ok, netf=of)
+        for k, v in r.items():
+            assert v == int(g["eval/" + k][s]), (s, k, v, int(g["eval/" + k][s]))
+        r2 = O.eval_batch(oc, og, x, t, float(g["sigma"][s]), cfg)          # eval.py's form: no detector / clean model
+        assert (r2["clean_correct"], r2["bd_correct"], r2["bd_ba"]) == (r["clean_correct"], r["bd_correct"], r["bd_ba"])
+    t0 = torch.zeros(5, dtype=torch.int64)                                   # only target-class images: nothing to trigger
+    assert O.eval_batch(oc, og, x[:5], t0, 0.5, cfg, clean=ok, netf=of)["bd_n"] == 0
+    # ---- victim step, then clean-classifier step on the same (updated) classifier
+    vi, vl = (int(v) for v in g["victim/seeds"])
+    x = synth_images(48, 32, vi)
+    t = torch.randint(0, 10, (48,), generator=torch.Generator().manual_seed(vl))
+    t[:6] = 0
+    names = O.trainable_names(oc)
+    oc_start = {k: v.clone() for k, v in oc.items()}
+    for tag, pz, ng in (("victim", torch.from_numpy(g["victim/poisoned"]), og), ("cleanclf", None, None)):
+        oc = {k: v.clone() for k, v in oc_start.items()}            # both steps from the same start state
+        bufs = [None] * len(names)
+        r = O.victim_step(oc, bufs, x, t, cfg, netg=ng, poisoned=pz, sigma=float(g["victim/sigma"]))
+        assert abs(r["loss"] - float(g[tag + "/loss"])) < 1e-5 and r["correct"] == int(g[tag + "/correct"])
+        assert abs(r["gnorm"] - float(g[tag + "/gnorm"])) < 1e-4 * float(g[tag + "/gnorm"])
+        # Gradient tolerance 5e-3: the triggered images differ by ~1e-6 between the reference's FFT low-pass and the
+        # oracle's closed form P X P^T, and this freshly initialised train-mode network amplifies a 1e-6
+        # perturbation of 3 of the 48 images into a 1.2e-3 relative change of the stem gradient (measured with the
+        # reference module itself; without triggered images the oracle's gradients equal the module's bit for bit).
+        num = den = 0.0       # (relative L2 over the sampled entries of all tensors: single entries move more)
+        for k, v in zip(names, r["grads"]):
+            d = v.double().flatten()[g["%s/gp/%s/idx" % (tag, k)]].numpy() - g["%s/gp/%s/val" % (tag, k)]
+            num, den = num + float((d ** 2).sum()), den + float((g["%s/gp/%s/val" % (tag, k)] ** 2).sum())
+            assert abs(float(v.double().norm()) - float(g["%s/gp/%s/l2" % (tag, k)])) < 5e-3 * float(g["%s/gp/%s/l2" % (tag, k)]) + 1e-9, k
+        assert (num / den) ** 0.5 < (5e-3 if tag == "victim" else 1e-5), (tag, (num / den) ** 0.5)
+        check_summary(g, tag + "/after", oc.items(), 1e-4)
+    assert r["num_bd"] == 0

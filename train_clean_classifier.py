@@ -2,7 +2,6 @@
 (reference train_clean_classifier.py:75-121 loop, :153-160 checkpoint keys, :191-193 path
 <checkpoints>/<saving_prefix>/<dataset>/<dataset>_<saving_prefix>.pth.tar)."""
 import os
-import shutil
 
 import torch
 
@@ -24,7 +23,10 @@ def get_model(opt):
 def train(netC, optimizerC, schedulerC, train_dl, tf_writer, epoch, opt, step=None):
     print(" Train:")
     netC.train()
-    step = step or netC.__dict__.setdefault("_clf_step", ClassifierStep(netC, opt))
+    step = step or netC.__dict__.get("_clf_step")
+    if step is None:
+        pg = torch.distributed.group.WORLD if torch.distributed.is_initialized() else None
+        step = netC.__dict__["_clf_step"] = ClassifierStep(netC, opt, process_group=pg)
     step.read_metrics(reset=True) if step.N else None
     total = 0
     for batch_idx, (inputs, targets) in enumerate(train_dl):
@@ -51,14 +53,17 @@ def eval(netC, optimizerC, schedulerC, test_dl, best_clean_acc, tf_writer, epoch
         n += len(inputs)
         correct += int((preds.argmax(1).cpu() == targets).sum())
         progress_bar(batch_idx, len(test_dl), "Clean Acc: {:.4f} - Best: {:.4f}".format(correct * 100.0 / n, best_clean_acc))
+    if torch.distributed.is_initialized():   # every rank evaluated its shard of the test set
+        n, correct = cdist.all_reduce_counters([n, correct], device=opt.device)
     acc = correct * 100.0 / n
     tf_writer.add_scalars("Test Accuracy", {"Clean": acc}, epoch)
     if acc > best_clean_acc:
         print(" Saving...")
         best_clean_acc = acc
-        api.sync_momentum_to_optimizer(optimizerC, netC)
-        torch.save({"netC": netC.state_dict(), "schedulerC": schedulerC.state_dict(), "optimizerC": optimizerC.state_dict(),
-                    "best_clean_acc": acc, "epoch_current": epoch}, opt.ckpt_path)
+        if int(os.environ.get("RANK", 0)) == 0:
+            api.sync_momentum_to_optimizer(optimizerC, netC)
+            torch.save({"netC": netC.state_dict(), "schedulerC": schedulerC.state_dict(),
+                        "optimizerC": optimizerC.state_dict(), "best_clean_acc": acc, "epoch_current": epoch}, opt.ckpt_path)
     return best_clean_acc
 
 
@@ -68,7 +73,10 @@ def main():
     rank, local_rank, world = cdist.init()
     if opt.device == "cuda":
         opt.device = "cuda:%d" % local_rank
-    train_dl, test_dl = get_dataloader(opt, True), get_dataloader(opt, False, shuffle=False)
+    if opt.seed is not None:
+        torch.manual_seed(opt.seed)
+    train_dl = get_dataloader(opt, True, rank=rank, world=world)
+    test_dl = get_dataloader(opt, False, shuffle=False, rank=rank, world=world)
     netC, optimizerC, schedulerC = get_model(opt)
     mode = opt.saving_prefix
     opt.ckpt_folder = os.path.join(opt.checkpoints, mode, opt.dataset)
@@ -76,16 +84,21 @@ def main():
     opt.log_dir = os.path.join(opt.ckpt_folder, "log_dir")
     best, epoch_current = 0.0, 0
     if opt.continue_training and os.path.exists(opt.ckpt_path):
-        sd = torch.load(opt.ckpt_path, map_location=opt.device, weights_only=False)
+        sd = torch.load(opt.ckpt_path, map_location=opt.device, weights_only=True)
         netC.load_state_dict(sd["netC"])
         optimizerC.load_state_dict(sd["optimizerC"])
         schedulerC.load_state_dict(sd["schedulerC"])
         api.load_momentum_from_optimizer(optimizerC, netC)
         best, epoch_current = sd["best_clean_acc"], sd["epoch_current"]
     else:
-        shutil.rmtree(opt.ckpt_folder, ignore_errors=True)
-    os.makedirs(opt.log_dir, exist_ok=True)
-    tf_writer = SummaryWriter(log_dir=opt.log_dir)
+        cdist.fresh_start(opt.ckpt_folder, rank)
+    if world > 1:
+        cdist.broadcast_module(netC)
+    if rank == 0:
+        os.makedirs(opt.log_dir, exist_ok=True)
+        tf_writer = SummaryWriter(log_dir=opt.log_dir)
+    else:
+        tf_writer = cdist.NullWriter()
     for epoch in range(epoch_current, opt.n_iters):
         print("Epoch {}:".format(epoch + 1))
         train(netC, optimizerC, schedulerC, train_dl, tf_writer, epoch, opt)

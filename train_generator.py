@@ -12,7 +12,6 @@ every rank a disjoint shard of each epoch and averages the gradients over RCCL (
 """
 import os
 import random
-import shutil
 
 import numpy as np
 import torch
@@ -189,7 +188,6 @@ def main():
     opt.ckpt_folder = os.path.join(opt.checkpoints, "{}_clean".format(mode), opt.dataset)
     opt.ckpt_path = os.path.join(opt.ckpt_folder, "{}_{}_clean.pth.tar".format(opt.dataset, mode))
     opt.log_dir = os.path.join(opt.ckpt_folder, "log_dir")
-    create_dir(opt.log_dir)
 
     opt.F_ckpt_path = detector_checkpoint_path(opt)
     print(f"Loading {opt.F_model} at {opt.F_ckpt_path}")
@@ -206,7 +204,7 @@ def main():
     if not os.path.exists(load_path):
         print("Error: {} not found".format(load_path))
         exit()
-    clean_model.load_state_dict(torch.load(load_path, map_location=opt.device, weights_only=False)["netC"])
+    clean_model.load_state_dict(torch.load(load_path, map_location=opt.device, weights_only=True)["netC"])
     clean_model.eval()
 
     if opt.continue_training:
@@ -214,7 +212,7 @@ def main():
             print("Pretrained model doesnt exist")
             exit()
         print("Continue training!!")
-        sd = torch.load(opt.ckpt_path, map_location=opt.device, weights_only=False)
+        sd = torch.load(opt.ckpt_path, map_location=opt.device, weights_only=True)
         netC.load_state_dict(sd["netC"])
         optimizerC.load_state_dict(sd["optimizerC"])
         schedulerC.load_state_dict(sd["schedulerC"])
@@ -231,13 +229,15 @@ def main():
         print("Train from scratch!!!")
         best = [0.0] * 6
         epoch_current = 0
-        if rank == 0:
-            shutil.rmtree(opt.ckpt_folder, ignore_errors=True)   # the reference wipes the folder too (:562)
-        create_dir(opt.log_dir)
+        cdist.fresh_start(opt.ckpt_folder, rank)   # the reference wipes the folder too (:562); rank 0 only, then a barrier
     if world > 1:
         for m in (netC, netG, clean_model, netF):
             cdist.broadcast_module(m)
-    tf_writer = SummaryWriter(log_dir=opt.log_dir)
+    if rank == 0:    # one writer, one checkpoint file: rank 0's (every rank holds the same replicas)
+        create_dir(opt.log_dir)
+        tf_writer = SummaryWriter(log_dir=opt.log_dir)
+    else:
+        tf_writer = cdist.NullWriter()
 
     for epoch in range(epoch_current, opt.n_iters):
         print("Epoch {}:".format(epoch + 1))

@@ -1,7 +1,6 @@
 """Victim training on data poisoned by the frozen generator (reference train_victim.py:93-165 loop,
 :168-231 eval, :221-229 checkpoint keys; dataset flags from utils/dataloader_cleanbd.py:131-158)."""
 import os
-import shutil
 
 import torch
 
@@ -24,7 +23,10 @@ def get_model(opt):
 def train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt):
     print(" Train:")
     netC.train()
-    step = netC.__dict__.setdefault("_clf_step", ClassifierStep(netC, opt, netG))
+    step = netC.__dict__.get("_clf_step")
+    if step is None:
+        pg = torch.distributed.group.WORLD if torch.distributed.is_initialized() else None
+        step = netC.__dict__["_clf_step"] = ClassifierStep(netC, opt, netG, process_group=pg)
     if step.N:
         step.read_metrics(reset=True)
     total = 0
@@ -60,14 +62,18 @@ def eval(netC, optimizerC, schedulerC, netG, test_dl, best_clean_acc, best_bd_ac
         acc_clean, acc_bd = correct * 100.0 / n, bd * 100.0 / max(nb, 1)
         progress_bar(batch_idx, len(test_dl), "Clean Acc: {:.4f} - Best: {:.4f} | Bd Acc: {:.4f} - Best: {:.4f}".format(
             acc_clean, best_clean_acc, acc_bd, best_bd_acc))
+    if torch.distributed.is_initialized():   # every rank evaluated its shard of the test set
+        n, nb, correct, bd = cdist.all_reduce_counters([n, nb, correct, bd], device=opt.device)
+        acc_clean, acc_bd = correct * 100.0 / n, bd * 100.0 / max(nb, 1)
     tf_writer.add_scalars("Test Accuracy", {"Clean": acc_clean, "Bd": acc_bd}, epoch)
     if acc_clean > best_clean_acc:
         print(" Saving...")
         best_clean_acc, best_bd_acc = acc_clean, acc_bd
-        api.sync_momentum_to_optimizer(optimizerC, netC)
-        torch.save({"netC": netC.state_dict(), "schedulerC": schedulerC.state_dict(), "optimizerC": optimizerC.state_dict(),
-                    "netG": netG.state_dict(), "best_clean_acc": acc_clean, "best_bd_acc": acc_bd, "epoch_current": epoch},
-                   opt.ckpt_path)
+        if int(os.environ.get("RANK", 0)) == 0:
+            api.sync_momentum_to_optimizer(optimizerC, netC)
+            torch.save({"netC": netC.state_dict(), "schedulerC": schedulerC.state_dict(), "optimizerC": optimizerC.state_dict(),
+                        "netG": netG.state_dict(), "best_clean_acc": acc_clean, "best_bd_acc": acc_bd,
+                        "epoch_current": epoch}, opt.ckpt_path)
     return best_clean_acc, best_bd_acc
 
 
@@ -77,8 +83,14 @@ def main():
     rank, local_rank, world = cdist.init()
     if opt.device == "cuda":
         opt.device = "cuda:%d" % local_rank
-    train_dl = get_dataloader(opt, True, poisoned=True)
-    test_dl = get_dataloader(opt, False, shuffle=False, poisoned=True)
+    if opt.seed is not None:
+        import random
+        import numpy as np
+        torch.manual_seed(opt.seed)
+        np.random.seed(opt.seed + rank)
+        random.seed(opt.seed)     # the poisoned index set must be the same on every rank (it is also broadcast)
+    train_dl = get_dataloader(opt, True, poisoned=True, rank=rank, world=world)
+    test_dl = get_dataloader(opt, False, shuffle=False, poisoned=True, rank=rank, world=world)
     netC, optimizerC, schedulerC, netG = get_model(opt)
     mode = opt.saving_prefix
     opt.ckpt_folder = os.path.join(opt.checkpoints, mode, opt.dataset)
@@ -89,22 +101,27 @@ def main():
     if not os.path.exists(load_path):
         print("Error: {} not found".format(load_path))
         exit()
-    netG.load_state_dict(torch.load(load_path, map_location=opt.device, weights_only=False)["netG"])
+    netG.load_state_dict(torch.load(load_path, map_location=opt.device, weights_only=True)["netG"])
     netG.eval()
     netG.requires_grad_(False)      # :279-280
     best_clean_acc = best_bd_acc = 0.0
     epoch_current = 0
     if opt.continue_training and os.path.exists(opt.ckpt_path):
-        sd = torch.load(opt.ckpt_path, map_location=opt.device, weights_only=False)
+        sd = torch.load(opt.ckpt_path, map_location=opt.device, weights_only=True)
         netC.load_state_dict(sd["netC"])
         optimizerC.load_state_dict(sd["optimizerC"])
         schedulerC.load_state_dict(sd["schedulerC"])
         api.load_momentum_from_optimizer(optimizerC, netC)
         best_clean_acc, best_bd_acc, epoch_current = sd["best_clean_acc"], sd["best_bd_acc"], sd["epoch_current"]
     else:
-        shutil.rmtree(opt.ckpt_folder, ignore_errors=True)
-    os.makedirs(opt.log_dir, exist_ok=True)
-    tf_writer = SummaryWriter(log_dir=opt.log_dir)
+        cdist.fresh_start(opt.ckpt_folder, rank)
+    if world > 1:
+        cdist.broadcast_module(netC)
+    if rank == 0:
+        os.makedirs(opt.log_dir, exist_ok=True)
+        tf_writer = SummaryWriter(log_dir=opt.log_dir)
+    else:
+        tf_writer = cdist.NullWriter()
     for epoch in range(epoch_current, opt.n_iters):
         print("Epoch {}:".format(epoch + 1))
         train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt)
