@@ -317,7 +317,10 @@ def pytorch_rocm_baseline(device, steps=10, budget_s=90.0):
         rng = np.random.default_rng(0)
 
         def one():
-            rnd = O.StepRandomness(int(np.sum(rng.random(n_trg) < 0.5)), 0.5, 0.6, [_aug_draw(rng, bs) for _ in range(5)])
+            # num_bd fixed at its expectation (6 of ~13 target-class images): every new poisoned-sub-batch size is
+            # a new set of convolution shapes for MIOpen to select / compile kernels for, which a 10-step sample
+            # would mostly measure (302 ms/step with num_bd drawn per step, vs the figure reported here)
+            rnd = O.StepRandomness(min(6, n_trg), 0.5, 0.6, [_aug_draw(rng, bs) for _ in range(5)])
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
                 O.alternated_step(netc, netg, clean, netf, bufs_c, bufs_g, x, t, rnd, O.StepConfig(), as_written=True,
                                   aug_fn=O.post_tensor_transform_batched)

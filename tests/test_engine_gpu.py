@@ -548,7 +548,8 @@ def test_trajectory_vs_reference_trace(mods, golden, name, steps):
 
     `trajectory_lr2e3` (--lr_C 2e-3 --lr_G 2e-3), 100 steps: exponential moving averages (alpha 0.1) of loss_c,
     clean_model_loss and loss_l2 within 2 % of the reference's at EVERY step; loss_ce -- whose raw curve
-    alternates between ~0 and ~2 with the recorded blur sigma of the step -- within 2 % + 0.02; per-step
+    alternates between ~0 and ~2 with the recorded blur sigma of the step -- within 2 % + 0.02 up to step 60 and
+    10 % + 0.02 after; per-step
     counters within 4 images of 32 and their 100-step totals within 1.5 %.  (The fp32 oracle driven with the
     CPU bf16 emulation, the idealised form of this design, measures 0.23 % / 0 % / 0.14 % and 7 % on loss_ce's
     EMA at step 99 = 0.05 absolute.)
@@ -590,7 +591,12 @@ def test_trajectory_vs_reference_trace(mods, golden, name, steps):
         dev = np.abs(e_o - e_r) - floor
         worst = int(np.argmax(dev / np.maximum(np.abs(e_r), 1e-9)))
         report[k] = (float((dev / np.maximum(np.abs(e_r), 1e-9)).max()), worst)
-        assert np.all(dev <= rel * np.abs(e_r)), (name, k, report[k], e_o[worst], e_r[worst])
+        tol = np.full(steps, rel)
+        if k == "loss_ce" and tight:
+            tol[60:] = 0.10      # past step 60 loss_ce alternates 0 <-> 2 with the step's blur sigma and small
+            #                      differences are amplified: the CPU bf16 emulation itself is 7 % off fp32 at step 99,
+            #                      HIP runs measured 3-6 % (they differ run to run: fp32 atomics reorder sums)
+        assert np.all(dev <= tol * np.abs(e_r)), (name, k, report[k], e_o[worst], e_r[worst])
     print(name, "max relative EMA deviations (value, step):", report)
     for k in ("clean_correct", "bd_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr", "train_correct"):
         o, r = np.array(ours[k], dtype=np.float64), g["trace/" + k][:steps]
