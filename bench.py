@@ -48,7 +48,7 @@ TILE_NAMES = {1: "conv_gemm_kernel<128,128>", 2: "conv_gemm_kernel<128,64>", 3: 
               6: "conv3x3_halo1_kernel<256,64>", 7: "conv3x3_halo1_kernel<128,128>", 8: "conv3x3_halo1_kernel<128,64>",
               9: "conv3x3_halo_kernel<64,64>", 10: "conv3x3_dma_kernel<64>", 11: "conv3x3_dma_kernel<32>",
               12: "conv_gather_dma_kernel<64>", 13: "conv_gather_dma_kernel<32>", 14: "conv3x3_dma_kernel<64,256px>",
-              15: "conv_c8_kernel"}
+              15: "conv_c8_kernel", 16: "conv3x3_dma_kernel<64,256px,w64>"}
 
 
 def log(msg):
@@ -442,13 +442,15 @@ def main():
     for i in range(args.steps):
         x, t = batches[i % len(batches)]
         st.run(x, t)
+    host_s = time.perf_counter() - t0          # launches enqueued (the device is still working them off)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
-    log("timed region: %.3f s (%.3f ms/step)" % (elapsed, elapsed / args.steps * 1e3))
+    log("timed region: %.3f s (%.3f ms/step; host enqueue %.3f ms/step)" % (elapsed, elapsed / args.steps * 1e3,
+                                                                              host_s / args.steps * 1e3))
     metrics = st.read_metrics()
     finite = all(np.isfinite(v) for v in metrics.values())
 

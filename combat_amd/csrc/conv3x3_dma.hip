@@ -21,6 +21,7 @@
 // as conv_common.hpp's) is wave-private: each wave transposes its 32 pixels x BN channels through LDS
 // and its operand fetches are issued four steps before the main loop ends.
 #include "conv_dma_epilogue.hpp"
+#include <stdlib.h>
 
 #ifdef COMBAT_STAMPS   // in-kernel phase stamps of profiling builds: the buffer pointer travels as a kernel argument
 static unsigned long long *g_stamps_dma_host = nullptr;
@@ -46,13 +47,15 @@ struct DmaParams {
     int m_fastest;               // order of an XCD's contiguous tile range (each XCD has its own L2)
     int PQ, nchunks;
     unsigned src_bytes, w_bytes;
+    int flavour;                  // epilogue specialisation (conv_dma_epilogue.hpp), -1: generic
+    int w_prefetch;               // warm the XCD's L2 with this channel tile's weight rows at kernel start (see the body)
     unsigned long long *stamps;   // profiling builds only
 };
 
-// geometry class of a tile of 32 * NW pixels (NW waves of 32 pixels), keyed by the tile width
-template <int TW, int NW>
+// geometry class of a tile of RPW * NW pixels (NW waves of RPW = 32 or 64 pixels), keyed by the tile width
+template <int TW, int NW, int RPW = 32>
 struct DGeo {
-    static constexpr int BM = 32 * NW;
+    static constexpr int BM = RPW * NW;
     static constexpr int TH = TW == 16 ? BM / 16 : (TW == 8 ? 8 : 4);
     static constexpr int TI = BM / (TW * TH);
     static constexpr int HH = TH + 2;
@@ -67,7 +70,7 @@ struct DGeo {
     static constexpr int HPW = (HROWS + 8 * NW - 1) / (8 * NW);  // 1-KiB DMA pieces (8 rows) per wave
     static constexpr int HBYTES = HPW * NW * 1024;               // every wave issues the same number of pieces
     static constexpr int TW_SHIFT = TW == 16 ? 4 : (TW == 8 ? 3 : 2);
-    static constexpr int TH_SHIFT = TH == 16 ? 4 : (TH == 8 ? 3 : 2);
+    static constexpr int TH_SHIFT = TH == 32 ? 5 : (TH == 16 ? 4 : (TH == 8 ? 3 : 2));
 };
 
 template <int VM>
@@ -84,10 +87,17 @@ __device__ __forceinline__ void block_barrier() {
 // HB = halo images in LDS: 1 for single-chunk layers (C = 64), 2 otherwise (the next chunk's patch is
 // DMA'd while the current one is consumed)
 // NW = waves per workgroup (4: 128-pixel tiles; 8: 256-pixel tiles, which halve the weight DMA per MFMA)
-template <int BN, int TW, int HB, int NW>
+// RPW = pixels per wave.  32: a wave's register tile is 32 pixels x BN channels.  64: 64 x BN -- per MFMA half the
+//       weight-fragment LDS reads and half the weight DMA of the 32-pixel form (LDS traffic per FLOP is set by the
+//       wave tile: (4 + 4) instead of (2 + 4) fragment reads per 16 MFMAs), and a 256-pixel workgroup of four waves:
+//       512 workgroups for a 64 -> 64 layer on 32 x 32 maps = ONE round at two per CU, where the 128-pixel tiles need
+//       1.33 rounds at three.  Its epilogue runs as two 32-pixel halves with operand fetches issued after the loop.
+template <int BN, int TW, int HB, int NW, int RPW>
 __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
-    using T = TileCfg<128, BN, 4>;  // shape of ONE wave's share: 32 pixels x all BN channels (whatever NW is)
-    using G = DGeo<TW, NW>;
+    using T = TileCfg<4 * RPW, BN, 4>;  // shape of ONE wave's share: RPW pixels x all BN channels (whatever NW is)
+    using TE = TileCfg<128, BN, 4>;     // the epilogue's unit: 32 pixels x BN channels
+    using G = DGeo<TW, NW, RPW>;
+    constexpr bool WIDE = RPW == 64;
     constexpr int WPW = BN / (8 * NW);      // weight DMA pieces per wave and step
     constexpr int WBYTES = BN * 128;        // one ring slot
     constexpr int HBYTES = G::HBYTES;
@@ -102,16 +112,25 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
 #endif
 
     int tile_m, tile_n;
+    int pf_rank = 0, pf_size = 1;   // this workgroup's place among the workgroups of its XCD that share its channel tile
     {
         const int nb = gridDim.x, bid = blockIdx.x;
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+        const int swz = base + idx;
         if (p.m_fastest) {   // weights outweigh the input: an XCD's tiles share few weight rows, all pixels
             tile_m = swz % p.tiles_m;
             tile_n = swz / p.tiles_m;
+            const int lo = base > tile_n * p.tiles_m ? base : tile_n * p.tiles_m;
+            const int hi = base + cnt < (tile_n + 1) * p.tiles_m ? base + cnt : (tile_n + 1) * p.tiles_m;
+            pf_rank = swz - lo;
+            pf_size = hi - lo;
         } else {
             tile_n = swz % p.tiles_n;
             tile_m = swz / p.tiles_n;
+            const int first = base + (tile_n - base % p.tiles_n + p.tiles_n) % p.tiles_n;
+            pf_rank = (swz - first) / p.tiles_n;
+            pf_size = (base + cnt - 1 - first) / p.tiles_n + 1;
         }
     }
     const int n0 = tile_n * BN;
@@ -148,6 +167,23 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     issue_w(0, 0, 0);
     issue_w(1, 0, 1);
     issue_w(2, 0, 2);
+    // ---- weight rows -> this XCD's L2, now.  The loop asks for a tap's weight tile three taps (~1000 cycles) ahead;
+    // in the step the weights come from HBM (400 MB of other tensors pass between two uses of a layer), a round trip
+    // several times that, and a 512-channel layer spends 72 steps waiting for it: 20 us with the weights in cache,
+    // 33 us cold (tools/conv_bench.py).  Every 128-byte line of the channel tile's rows is touched once here by a
+    // 16-byte LDS-DMA into a scratch KB nobody reads -- no registers, no waits; the lines are divided among the
+    // workgroups of this XCD that share the channel tile -- and has arrived by the time the halo patch has.
+    if (p.w_prefetch) {
+        const int lpr = (9 * C * 2) >> 7;                  // 128-byte lines per weight row (C is a multiple of 64)
+        const int nlines = BN * lpr;
+        unsigned char *dummy = smem + HB * HBYTES + 3 * WBYTES;
+        for (int j = tid; pf_rank + pf_size * (j - lane) < nlines; j += 64 * NW) {
+            const int l = pf_rank + pf_size * j;
+            const int row = l / lpr, col = l - row * lpr;
+            const unsigned off = l < nlines ? (unsigned)((n0 + row) * a.kpad * 2 + col * 128) : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)dummy, 16, off, 0, 0, 0);
+        }
+    }
     // ---- per-lane DMA source offsets of the halo patch (bytes): the chunk term is added through the scalar offset
     unsigned hvoff[HPW];
 #pragma unroll
@@ -175,7 +211,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     int pa[2][T::FM][3];
 #pragma unroll
     for (int j = 0; j < T::FM; ++j) {
-        const int pj = wid * 32 + j * 16 + (lane & 15);
+        const int pj = wid * RPW + j * 16 + (lane & 15);
         const int tx = pj & (TW - 1), ty = (pj >> G::TW_SHIFT) & (G::TH - 1), ti = pj >> (G::TW_SHIFT + G::TH_SHIFT);
         const int r0 = (ti * G::HH + ty) * G::HWP + tx;
 #pragma unroll
@@ -231,17 +267,20 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     // in the middle of the main loop's last chunk, so that their latency is covered by the remaining
     // MFMA steps -- the counted waits of those steps include them.
     // ---- fused epilogue (conv_dma_epilogue.hpp): operand fetches are issued PF_T taps before the loop ends
-    using EC = EpiCfg<T>;
-    constexpr int NPF = EC::NPF;
+    using EC = EpiCfg<TE>;
+    constexpr int NPF = WIDE ? 0 : EC::NPF;
     const unsigned dst_bytes = (unsigned)(a.N * p.PQ) * (unsigned)a.K * 2u;
-    EpiRegs<T> epi;
-    epi_init<T>(epi, lane, wid, n0, [&](int row) -> long {
+    auto tile_row_off = [&](int row) -> long {   // element offset of tile pixel `row` in the dst-shaped tensors, or -1
         const int tx = row & (TW - 1), ty = (row >> G::TW_SHIFT) & (G::TH - 1);
         const int img = img0 + (row >> (G::TW_SHIFT + G::TH_SHIFT));
         return img < a.N ? (long)((img * H + oy0 + ty) * W + ox0 + tx) * a.K : -1;
-    });
+    };
+    EpiRegs<TE> epi;
+    if (!WIDE) epi_init<TE>(epi, lane, wid, n0, tile_row_off);
     const bool ragged = G::TI > 1 && img0 + G::TI > a.N;
-    auto epilogue_fetch = [&]() __attribute__((always_inline)) { epi_fetch<T>(epi, a, dst_bytes, lane, n0); };
+    auto epilogue_fetch = [&]() __attribute__((always_inline)) {
+        if (!WIDE) epi_fetch<TE>(epi, a, dst_bytes, lane, n0);
+    };
 
     // ---- main loop, software pipelined.  Loop position t of a chunk = filter tap; its weights live in
     // ring slot t % 3 and are DMA'd three positions ahead.  A position is two k-steps; its fragments
@@ -255,6 +294,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     constexpr int PF_T = 4;
     const int nchunks = p.nchunks;
     bf16x8_t fpA[T::FM], fwA[T::FN], fpB[T::FM], fwB[T::FN];
+    static_assert(T::FM == RPW / 16 && T::FN == BN / 16, "wave tile");
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 #ifdef COMBAT_STAMPS
@@ -321,15 +361,39 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
 
     // ---- epilogue: accumulators -> this wave's fp32 LDS image (the operand images are dead once every
     // wave has passed the barrier) -> row-major items
-    block_barrier();
-    epi_finish<T>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged, p.PQ);
+    if constexpr (!WIDE) {
+        block_barrier();
+        epi_finish<TE>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged, p.PQ, p.flavour);
+    } else {
+        // two 32-pixel halves, one after the other (both halves' operand sets at once would be 136 registers on
+        // top of the 64 accumulators); the first half's fetches go out before the barrier that frees the operand images
+        epi_init<TE>(epi, lane, wid, n0, [&](int row) -> long { return tile_row_off(wid * 64 + (row - wid * 32)); });
+        epi_fetch<TE>(epi, a, dst_bytes, lane, n0);
+        block_barrier();
+        f32x4_t half[T::FN][2];
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i) {
+            half[i][0] = acc[i][0];
+            half[i][1] = acc[i][1];
+        }
+        epi_finish<TE>(epi, smem, half, a, dst_bytes, lane, wid, n0, ((long)tile_m * NW + wid) * 2, ragged, p.PQ, p.flavour);
+        epi_init<TE>(epi, lane, wid, n0, [&](int row) -> long { return tile_row_off(wid * 64 + 32 + (row - wid * 32)); });
+        epi_fetch<TE>(epi, a, dst_bytes, lane, n0);
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i) {
+            half[i][0] = acc[i][2];
+            half[i][1] = acc[i][3];
+        }
+        epi_finish<TE>(epi, smem, half, a, dst_bytes, lane, wid, n0, ((long)tile_m * NW + wid) * 2 + 1, ragged, p.PQ, p.flavour);
+    }
     DSTAMP(4);
 }
 
 // (the body is a device function: the host pass cannot see the buffer-resource type it uses)
-template <int BN, int TW, int HB, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : (HB == 1 ? 3 : 2)) void conv3x3_dma_kernel(const DmaParams p) {
-    conv3x3_dma_body<BN, TW, HB, NW>(p);
+template <int BN, int TW, int HB, int NW, int RPW>
+__global__ __launch_bounds__(64 * NW, NW == 8 || (RPW == 64 && HB == 2) ? 1 : 2)
+void conv3x3_dma_kernel(const DmaParams p) {
+    conv3x3_dma_body<BN, TW, HB, NW, RPW>(p);
 }
 
 int geo_tw(const combat_conv_args *a) {
@@ -351,9 +415,9 @@ bool applicable(const combat_conv_args *a, int BN) {
     return geo_tw(a) != 0;
 }
 
-template <int TW, int NW>
+template <int TW, int NW, int RPW>
 void fill(const combat_conv_args *a, int BN, DmaParams &p) {
-    using G = DGeo<TW, NW>;
+    using G = DGeo<TW, NW, RPW>;
     p.a = *a;
     p.tiles_x = a->W / TW;
     p.tiles_y = a->H / G::TH;
@@ -367,6 +431,9 @@ void fill(const combat_conv_args *a, int BN, DmaParams &p) {
     p.nchunks = a->C / 64;
     p.src_bytes = (unsigned)((long)a->N * a->H * a->W * a->C * 2);
     p.w_bytes = (unsigned)((long)a->rows_pad * a->kpad * 2);
+    p.flavour = epi_flavour_of(*a);
+    // (worth it where a channel tile's weight rows are many lines per workgroup step: >= 256 channels)
+    p.w_prefetch = a->C >= 256 && !getenv("COMBAT_NO_WPREFETCH");
 #ifdef COMBAT_STAMPS
     p.stamps = g_stamps_dma_host;
 #else
@@ -374,13 +441,13 @@ void fill(const combat_conv_args *a, int BN, DmaParams &p) {
 #endif
 }
 
-template <int BN, int TW, int HB, int NW>
+template <int BN, int TW, int HB, int NW, int RPW>
 int launch_hb(const DmaParams &p, hipStream_t st) {
-    using G = DGeo<TW, NW>;
-    constexpr int stage = HB * G::HBYTES + 3 * BN * 128;
+    using G = DGeo<TW, NW, RPW>;
+    constexpr int stage = HB * G::HBYTES + 3 * BN * 128 + 1024;   // (+ the weight prefetch's scratch KB)
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES / 4 * NW;
     constexpr int smem = stage > ep ? stage : ep;
-    auto kern = conv3x3_dma_kernel<BN, TW, HB, NW>;
+    auto kern = conv3x3_dma_kernel<BN, TW, HB, NW, RPW>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -392,22 +459,24 @@ int launch_hb(const DmaParams &p, hipStream_t st) {
     return COMBAT_OK;
 }
 
-template <int BN, int TW, int NW>
+template <int BN, int TW, int NW, int RPW = 32>
 int launch(const combat_conv_args *a, hipStream_t st) {
     DmaParams p;
-    fill<TW, NW>(a, BN, p);
-    return p.nchunks == 1 ? launch_hb<BN, TW, 1, NW>(p, st) : launch_hb<BN, TW, 2, NW>(p, st);
+    fill<TW, NW, RPW>(a, BN, p);
+    return p.nchunks == 1 ? launch_hb<BN, TW, 1, NW, RPW>(p, st) : launch_hb<BN, TW, 2, NW, RPW>(p, st);
 }
 
 int tile_bn(int tile) {
-    return tile == COMBAT_TILE_D128x64 || tile == COMBAT_TILE_D256x64 ? 64 : (tile == COMBAT_TILE_D128x32 ? 32 : 0);
+    return tile == COMBAT_TILE_D128x64 || tile == COMBAT_TILE_D256x64 || tile == COMBAT_TILE_D256W64 ? 64
+                                                                                                 : (tile == COMBAT_TILE_D128x32 ? 32 : 0);
 }
-int tile_bm(int tile) { return tile == COMBAT_TILE_D256x64 ? 256 : 128; }
+int tile_bm(int tile) { return tile == COMBAT_TILE_D256x64 || tile == COMBAT_TILE_D256W64 ? 256 : 128; }
 
 // tile height for a tile of bm pixels (0: the geometry does not exist)
 int geo_th(const combat_conv_args *a, int bm) {
     const int tw = geo_tw(a);
     if (!tw || (tw == 4 && bm == 256)) return 0;   // 16 images of 4x4 per tile: two halo images would not fit LDS
+    if (tw == 16 && bm == 256 && a->H % 16 != 0) return 0;
     const int th = tw == 16 ? bm / 16 : (tw == 8 ? 8 : 4);
     return a->H % th == 0 ? th : 0;
 }
@@ -425,6 +494,7 @@ int tiles_m_of(const combat_conv_args *a, int bm = 128) {
 int conv3x3d_pick(const combat_conv_args *a) {
     if (a->tile) {
         const int bn = tile_bn(a->tile);
+        if (a->tile == COMBAT_TILE_D256W64 && geo_tw(a) != 16) return 0;
         return bn && applicable(a, bn) && geo_th(a, tile_bm(a->tile)) ? a->tile : 0;
     }
     if (!applicable(a, 64)) return applicable(a, 32) ? COMBAT_TILE_D128x32 : 0;
@@ -458,6 +528,7 @@ int conv3x3d_launch(const combat_conv_args *a, int tile, hipStream_t st) {
         if (tw == 16) return launch<64, 16, 8>(a, st);
         return launch<64, 8, 8>(a, st);
     }
+    if (tile == COMBAT_TILE_D256W64) return tw == 16 ? launch<64, 16, 4, 64>(a, st) : COMBAT_EINVAL;
     if (bn == 64) {
         if (tw == 16) return launch<64, 16, 4>(a, st);
         if (tw == 8) return launch<64, 8, 4>(a, st);

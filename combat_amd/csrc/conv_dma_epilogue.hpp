@@ -69,17 +69,84 @@ __device__ __forceinline__ void epi_fetch(EpiRegs<T> &r, const combat_conv_args 
     }
 }
 
+// ---- epilogue flavours.  epi_finish's feature tests (which operand tensors exist, which mask form, which
+// statistics) are uniform per launch.  As run-time flags they cost every launch the VALU work of every
+// feature -- 1157 vector instructions per wave for a 32 x 64 tile, 4.8 k cycles of a 15 k-cycle workgroup
+// (in-kernel stamps), more than the nine MFMA taps of a 64-channel layer -- because a select is cheaper to
+// emit than a branch.  The launches of the step use a handful of combinations; those are compiled as
+// specialised bodies (features as template constants: absent ones vanish) behind ONE uniform switch on
+// `flavour`, anything else takes the generic body (FL < 0: all features tested at run time).
+enum : int {
+    EF_PRE = 1,          // add_pre tensor
+    EF_POST = 2,         // add_post tensor
+    EF_MASK = 4,         // mask_x tensor
+    EF_MASK_TAB = 8,     // kept-test on fma(x, scale, shift) (else on x itself: activated tensors / table-free masks)
+    EF_MUL_SCALE = 16,   // kept elements are multiplied by the table's scale (BatchNorm backward)
+    EF_PER_IMAGE = 32,   // mask / statistics tables per (image, channel): InstanceNorm
+    EF_ACT = 64,         // activated second output
+    EF_STATS1 = 128,     // sums / second moments of the stored values
+    EF_STATS2 = 256,     // sums / dz * xhat products (norm backward)
+    EF_BIAS = 512,
+    EF_NODST = 1024,     // no raw output tensor
+};
+
+// feature bits of a launch (host and device)
+__host__ __device__ inline int epi_flags_of(const combat_conv_args &a) {
+    int f = 0;
+    if (a.add_pre) f |= EF_PRE;
+    if (a.add_post) f |= EF_POST;
+    if (a.mask_x) {
+        f |= EF_MASK;
+        if (a.mask_scale && !a.mask_activated) f |= EF_MASK_TAB;
+        if (a.mask_mul_scale && a.mask_scale) f |= EF_MUL_SCALE;
+        if (a.mask_group_stride) f |= EF_PER_IMAGE;
+    }
+    if (a.act_dst) f |= EF_ACT;
+    if (a.stats_kind == 1) f |= EF_STATS1;
+    if (a.stats_kind == 2) f |= EF_STATS2;
+    if (a.bias) f |= EF_BIAS;
+    if (!a.dst) f |= EF_NODST;
+    return f;
+}
+
+// The specialised combinations (what the alternated step launches most, engine.py).  Only the KIND of epilogue is
+// a compile-time constant; which residual / bias operands exist and whether the raw tensor is stored stay uniform
+// run-time branches inside a body (kEpiRuntime bits): every extra body raises the kernel's register allocation
+// (the allocator sees one function: 180 registers with the generic body alone, 223 with three more, spills with 17).
+constexpr int kEpiRuntime = EF_PRE | EF_POST | EF_BIAS | EF_NODST;
+constexpr int kEpiFlavours[] = {
+    0,                                        // 0 plain store (+ residuals)
+    EF_ACT,                                   // 1 eval forward: (raw +) activated output
+    EF_STATS1,                                // 2 train forward: statistics of the stored values
+    EF_MASK | EF_MUL_SCALE,                   // 3 eval backward: activated mask x BatchNorm scale
+    EF_MASK | EF_MASK_TAB | EF_STATS2,        // 4 train backward (BatchNorm): mask from the raw tensor + norm-backward sums
+};
+constexpr int kNumEpiFlavours = sizeof(kEpiFlavours) / sizeof(int);
+
+// index into kEpiFlavours, or -1 (generic body)
+inline int epi_flavour_of(const combat_conv_args &a) {
+    const int f = epi_flags_of(a) & ~kEpiRuntime;
+    for (int i = 0; i < kNumEpiFlavours; ++i)
+        if (kEpiFlavours[i] == f) return i;
+    return -1;
+}
+
 // Call after a workgroup barrier that follows the last LDS read of the main loop (the wave images
 // overlay the operand images).  stats_row = this wave's row of the statistics array (< 0: the wave lies
 // entirely outside the tensor and owns no row); ragged = the wave
 // may own rows outside the tensor (their statistics count as zeros).
-template <typename T>
-__device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, const f32x4_t (&acc)[T::FN][T::FM],
-                                           const combat_conv_args &a, unsigned dst_bytes, int lane, int wid, int n0,
-                                           long stats_row, bool ragged, int PQ) {
+// FL >= 0: the launch's feature bits, known at compile time; FL < 0: read from the arguments.
+template <typename T, int FL>
+__device__ __forceinline__ void epi_finish_fl(EpiRegs<T> &er, unsigned char *smem, const f32x4_t (&acc)[T::FN][T::FM],
+                                              const combat_conv_args &a, unsigned dst_bytes, int lane, int wid, int n0,
+                                              long stats_row, bool ragged, int PQ) {
     constexpr int NC = EpiCfg<T>::NC, EQ = EpiCfg<T>::EQ, EPW = EpiCfg<T>::EPW;
+    constexpr bool RT = FL < 0;
+    const int fl = RT ? epi_flags_of(a) : (FL | (epi_flags_of(a) & kEpiRuntime));
+    const bool has_pre = fl & EF_PRE, has_post = fl & EF_POST, has_mask = fl & EF_MASK, mask_tab = fl & EF_MASK_TAB;
+    const bool mul_scale = fl & EF_MUL_SCALE, per_image = fl & EF_PER_IMAGE, has_act = fl & EF_ACT;
+    const bool kind1 = fl & EF_STATS1, kind2 = fl & EF_STATS2, has_bias = fl & EF_BIAS, has_dst = !(fl & EF_NODST);
     const int fr = lane & 15, fq = lane >> 4, ec = lane % NC, K = a.K;
-    const bool kind2 = a.stats_kind == 2;
     const __amdgpu_buffer_rsrc_t r_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, a.dst ? dst_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_act = __builtin_amdgcn_make_buffer_rsrc(a.act_dst, 0, a.act_dst ? dst_bytes : 0u, 0x00020000);
     float *ep = reinterpret_cast<float *>(smem) + wid * EPW;
@@ -90,28 +157,22 @@ __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, 
             *reinterpret_cast<f32x4_t *>(ep + (j * 16 + fr) * T::EPS + i * 16 + fq * 4) = acc[i][j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // a wave's LDS accesses execute in order
 
-    const bool has_mask = a.mask_x != nullptr, has_scale = a.mask_scale != nullptr, has_act = a.act_dst != nullptr;
-    const bool mul_scale = a.mask_mul_scale != 0;
-    const bool plain_test = !has_scale || a.mask_activated;   // kept-test on mask_x itself
-    const bool per_image = has_mask && a.mask_group_stride != 0;
     const int n = n0 + ec * 8;
-    float bias8[8], msc[8], msh[8], hrs[8], hmn[8], tsc[8], tsh[8];
+    // per-channel tables (mask tables in a backward launch, activation-output tables in a forward one: the
+    // pair that travelled with the operand prefetch)
+    float tsc[8], tsh[8], bias8[8], hrs[8], hmn[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        bias8[e] = hrs[e] = hmn[e] = 0.f;
-        tsc[e] = er.t_sc[e >> 2][e & 3];   // mask tables or activation-output tables
+        tsc[e] = er.t_sc[e >> 2][e & 3];
         tsh[e] = er.t_sh[e >> 2][e & 3];
-        msc[e] = plain_test ? 1.f : tsc[e];
-        msh[e] = plain_test ? 0.f : tsh[e];
+        bias8[e] = hrs[e] = hmn[e] = 0.f;
     }
-    if (a.bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
+    if (has_bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
     if (kind2 && !per_image) {
         load8f(a.xh_rstd + n, hrs);
         load8f(a.xh_mean + n, hmn);
     }
-    float mfac[8];   // factor of a kept element: the scale (BatchNorm backward) or 1
-#pragma unroll
-    for (int e = 0; e < 8; ++e) mfac[e] = mul_scale ? tsc[e] : 1.f;
+    const float mslope = a.mask_slope, aslope = a.act_slope;
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
@@ -121,22 +182,26 @@ __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, 
         const int r = (q * 64 + lane) / NC;
         float v[8], t[8], xm[8];
         load8f(ep + r * T::EPS + ec * 8, v);
-        unpack8v(er.e_pre[q], t);
+        if (has_pre) {
+            unpack8v(er.e_pre[q], t);
+            if (has_bias) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias8[e] + t[e];
+                for (int e = 0; e < 8; ++e) v[e] += bias8[e] + t[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += t[e];
+            }
+        } else if (has_bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+        }
         if (has_mask) {
             unpack8v(er.e_x[q], xm);
             if (per_image && er.evoff[q] != kDmaOob) {   // InstanceNorm: tables of this row's image (L2-resident)
                 const long g = (long)((er.evoff[q] >> 1) / (unsigned)K / (unsigned)PQ) * a.mask_group_stride + n;
-                if (has_scale) {
+                if (mask_tab || mul_scale) {
                     load8f(a.mask_scale + g, tsc);
                     load8f(a.mask_shift + g, tsh);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        msc[e] = plain_test ? 1.f : tsc[e];
-                        msh[e] = plain_test ? 0.f : tsh[e];
-                        mfac[e] = mul_scale ? tsc[e] : 1.f;
-                    }
                 }
                 if (kind2) {
                     load8f(a.xh_rstd + g, hrs);
@@ -144,26 +209,30 @@ __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, 
                 }
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e)   // msc = 1, msh = 0 without a table
-                v[e] *= fmaf(xm[e], msc[e], msh[e]) > 0.f ? mfac[e] : mfac[e] * a.mask_slope;
+            for (int e = 0; e < 8; ++e) {
+                const float test = mask_tab ? fmaf(xm[e], tsc[e], tsh[e]) : xm[e];
+                const float kept = mul_scale ? tsc[e] : 1.f;
+                v[e] *= test > 0.f ? kept : kept * mslope;
+            }
         }
-        unpack8v(er.e_post[q], t);
+        if (has_post) {
+            unpack8v(er.e_post[q], t);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += t[e];
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+        }
         packed[q] = pack8v(v);
+        float vr[8];
+        if (has_act || kind1 || kind2) unpack8v(packed[q], vr);   // the stored (rounded) values
         if (has_act) {   // the next layer's (eval BatchNorm + ReLU) prologue, applied to the stored value
             float y[8];
-            unpack8v(packed[q], y);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float qa = fmaf(y[e], tsc[e], tsh[e]);
-                y[e] = qa > 0.f ? qa : qa * a.act_slope;
+                const float qa = fmaf(vr[e], tsc[e], tsh[e]);
+                y[e] = qa > 0.f ? qa : qa * aslope;
             }
             packed_act[q] = pack8v(y);
         }
-        if (a.stats_kind) {
-            float vr[8];
-            unpack8v(packed[q], vr);
+        if (kind1 || kind2) {
             if (ragged && er.evoff[q] == kDmaOob) {   // rows beyond the last image count as zeros
 #pragma unroll
                 for (int e = 0; e < 8; ++e) vr[e] = 0.f;
@@ -183,13 +252,15 @@ __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, 
             }
         }
     }
+    if (has_dst) {
 #pragma unroll
-    for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed[q], r_dst, er.evoff[q], 0, 0);
+        for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed[q], r_dst, er.evoff[q], 0, 0);
+    }
     if (has_act) {
 #pragma unroll
         for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed_act[q], r_act, er.evoff[q], 0, 0);
     }
-    if (a.stats_kind && stats_row >= 0) {
+    if ((kind1 || kind2) && stats_row >= 0) {
         // one statistics row per wave (32 pixels).  Lanes with equal chunk differ by multiples of NC:
         // one pass through the wave's LDS image ([lane][16] partial sums; lane -> (chunk, value pair))
         // instead of log2(64 / NC) dependent cross-lane shuffles of 16 values each.
@@ -216,4 +287,22 @@ __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, 
 #pragma unroll
         for (int u = 0; u < VPL; ++u) orow[u] = tot[u];
     }
+}
+
+// dispatch on the launch's flavour (uniform): one specialised body runs
+template <typename T>
+__device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, const f32x4_t (&acc)[T::FN][T::FM],
+                                           const combat_conv_args &a, unsigned dst_bytes, int lane, int wid, int n0,
+                                           long stats_row, bool ragged, int PQ, int flavour) {
+#define COMBAT_EPI_CASE(i)                                                                                      \
+    case i:                                                                                                     \
+        epi_finish_fl<T, kEpiFlavours[i]>(er, smem, acc, a, dst_bytes, lane, wid, n0, stats_row, ragged, PQ);   \
+        break;
+    switch (flavour) {
+        COMBAT_EPI_CASE(0) COMBAT_EPI_CASE(1) COMBAT_EPI_CASE(2) COMBAT_EPI_CASE(3) COMBAT_EPI_CASE(4)
+    default:
+        epi_finish_fl<T, -1>(er, smem, acc, a, dst_bytes, lane, wid, n0, stats_row, ragged, PQ);
+    }
+#undef COMBAT_EPI_CASE
+    static_assert(kNumEpiFlavours == 5, "one case per flavour");
 }

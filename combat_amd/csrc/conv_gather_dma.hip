@@ -17,6 +17,7 @@
 // tile's pixels share their 1, 2 or 4 reachable taps and the others are skipped.
 // The epilogue is the shared DMA-kernel epilogue (conv_dma_epilogue.hpp).
 #include "conv_dma_epilogue.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,6 +34,8 @@ struct GatherParams {
     unsigned src_bytes, w_bytes, dst_bytes;
     int splits;                  // > 1: the reduction steps of a tile are divided among `splits` workgroups that
     float *ws;                   //      write fp32 slabs [split][tile][128][BN] here; conv_gather_finish_kernel combines
+    int flavour;                 // epilogue specialisation (conv_dma_epilogue.hpp), -1: generic
+    int w_prefetch;              // warm the XCD's L2 with this workgroup's weight rows at kernel start (conv3x3_dma.hip)
     unsigned long long *stamps;  // profiling builds only (-DCOMBAT_STAMPS): per workgroup, cycles per phase
 };
 
@@ -68,18 +71,27 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     int tile_m, tile_n, sp, tile;
+    int pf_rank = 0, pf_size = 1;   // this workgroup's place among the workgroups of its XCD that share its weight rows
     {
         const int ntile = p.tiles_m * p.tiles_n;
         const int nb = ntile, bid = blockIdx.x % ntile;
         sp = blockIdx.x / ntile;                       // slab of a split reduction (0 otherwise)
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+        tile = base + idx;
         if (p.m_fastest) {   // weights outweigh the input: an XCD's contiguous tiles share few weight rows, all pixels
             tile_m = tile % p.tiles_m;
             tile_n = tile / p.tiles_m;
+            const int lo = base > tile_n * p.tiles_m ? base : tile_n * p.tiles_m;
+            const int hi = base + cnt < (tile_n + 1) * p.tiles_m ? base + cnt : (tile_n + 1) * p.tiles_m;
+            pf_rank = tile - lo;
+            pf_size = hi - lo;
         } else {
             tile_n = tile % p.tiles_n;
             tile_m = tile / p.tiles_n;
+            const int first = base + (tile_n - base % p.tiles_n + p.tiles_n) % p.tiles_n;
+            pf_rank = (tile - first) / p.tiles_n;
+            pf_size = (base + cnt - 1 - first) / p.tiles_n + 1;
         }
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -151,6 +163,21 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
                 at_stage(q, [&](auto st) __attribute__((always_inline)) { issue_w(jw, cw, st); });
                 advance(jw, cw);
             }
+    }
+
+    // ---- weight rows of this workgroup's reduction steps -> the XCD's L2, now (see conv3x3_dma.hip: the ring asks
+    // for a step's weights two steps ahead, a fraction of an HBM round trip; in the step the weights are cold).
+    // A step's weights are one 128-byte line per row; lines [g_lo, g_lo + nsteps) of each of the BN rows, divided
+    // among the workgroups of this XCD that share them.
+    if (!FINISH && p.w_prefetch && !p.psplit && nsteps > 0) {
+        const int nlines = BN * nsteps;
+        unsigned char *dummy = smem + NS * SBYTES;
+        for (int j = tid; pf_rank + pf_size * (j - lane) < nlines; j += 256) {
+            const int l = pf_rank + pf_size * j;
+            const int row = l / nsteps, col = l - row * nsteps;
+            const unsigned off = l < nlines ? (unsigned)((n0 + row) * a.kpad * 2 + (g_lo + col) * 128) : kDmaOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)dummy, 16, off, 0, 0, 0);
+        }
     }
 
     // destination pixel m -> (image, y, x).  Shifts when P*Q and Q are powers of two (every CIFAR / CelebA
@@ -340,7 +367,7 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
                 acc[i][j] = v;
             }
         epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
-                      m0 + BM > p.M, p.PQ);
+                      m0 + BM > p.M, p.PQ, p.flavour);
         return;
     }
     // wait until step `g + 1` has landed while the `k` younger steps issued after it stay in flight
@@ -424,7 +451,7 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         return;
     }
     epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
-                  m0 + BM > p.M, p.PQ);
+                  m0 + BM > p.M, p.PQ, p.flavour);
 #ifdef COMBAT_STAMPS
     if (threadIdx.x == 0 && p.stamps) {
         p.stamps[blockIdx.x * 16 + 9] = GCLK() - c_loop_end;
@@ -526,7 +553,7 @@ __device__ __forceinline__ void conv_c8_body(const GatherParams &p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[ks][i]),
                                                                     __builtin_bit_cast(bf16x8_t, fp[ks][j]), acc[i][j], 0, 0, 0);
     epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
-                  m0 + BM > p.M, p.PQ);
+                  m0 + BM > p.M, p.PQ, p.flavour);
 }
 
 __global__ __launch_bounds__(256, 3) void conv_c8_kernel(const GatherParams p) { conv_c8_body<64>(p); }
@@ -573,6 +600,8 @@ int launch(const combat_conv_args *a, hipStream_t st) {
     const long need = (long)p.splits * p.tiles_m * p.tiles_n * 128 * BN * 4;
     if (p.splits > 1 && (!a->workspace || a->workspace_bytes < need)) p.splits = 1;
     p.ws = p.splits > 1 ? reinterpret_cast<float *>(a->workspace) : nullptr;
+    p.flavour = epi_flavour_of(*a);
+    p.w_prefetch = (long)a->C * p.ntaps >= 1024 && !getenv("COMBAT_NO_WPREFETCH");   // >= 16 lines per weight row
 #ifdef COMBAT_STAMPS
     p.stamps = g_stamps_gather_host;
 #else
@@ -580,7 +609,7 @@ int launch(const combat_conv_args *a, hipStream_t st) {
 #endif
     constexpr int stage = 128 * 128 + BN * 128;
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
-    constexpr int smem = 3 * stage > ep ? 3 * stage : ep;
+    constexpr int smem = (3 * stage > ep ? 3 * stage : ep) + 1024;   // (+ the weight prefetch's scratch KB)
     // (A six-stage ring for launches of at most one workgroup per CU -- ring depth is a template parameter --
     // changed nothing on the kernel alone and cost the step 1.5 %: a workgroup holding 144 KB of LDS keeps the
     // other streams' workgroups off its CU.  What bounds a lone workgroup is in-order issue, not DMA latency.)
@@ -638,6 +667,8 @@ int conv_c8_launch(const combat_conv_args *a, hipStream_t st) {
     p.dst_bytes = (unsigned)((long)p.M * a->K * 2);
     p.splits = 1;
     p.ws = nullptr;
+    p.flavour = epi_flavour_of(*a);
+    p.w_prefetch = 0;
     p.stamps = nullptr;
     constexpr int smem = EpiCfg<TileCfg<128, 64, 4>>::LDS_BYTES;
     static bool attr_set = false;

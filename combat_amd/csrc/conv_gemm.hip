@@ -312,7 +312,8 @@ int pick_tile(const combat_conv_args *a) {
         a->workspace_bytes >= conv_gather_dma_workspace(a))   // skinny layer: split reduction beats any single-workgroup tile
         return conv_gather_dma_bn(a) == 64 ? COMBAT_TILE_G128x64 : COMBAT_TILE_G128x32;
     if (const int halo = conv3x3_pick(a)) return halo;   // 3x3 / stride 1 with the patch held in LDS
-    if ((a->tile >= COMBAT_TILE_H256x64 && a->tile < COMBAT_TILE_G128x64) || a->tile == COMBAT_TILE_D256x64)
+    if ((a->tile >= COMBAT_TILE_H256x64 && a->tile < COMBAT_TILE_G128x64) || a->tile == COMBAT_TILE_D256x64 ||
+        a->tile == COMBAT_TILE_D256W64)
         return 0;   // a 3x3 tile was forced but does not apply
     if ((a->tile == 0 || a->tile == COMBAT_TILE_C8) && conv_c8_ok(a)) return COMBAT_TILE_C8;
     if (a->tile == COMBAT_TILE_C8) return 0;
@@ -352,6 +353,7 @@ extern "C" int combat_conv_stats_granule(int tile) {
         case COMBAT_TILE_G128x64:
         case COMBAT_TILE_G128x32:
         case COMBAT_TILE_C8:
+        case COMBAT_TILE_D256W64:
         case COMBAT_TILE_D256x64: return 32;
         case COMBAT_TILE_64x64:
         case COMBAT_TILE_64x128:
@@ -363,7 +365,7 @@ extern "C" int combat_conv_stats_granule(int tile) {
 extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows, int32_t *rows_per_image) {
     if (!a || !rows || !rows_per_image) return COMBAT_EINVAL;
     const int tile = pick_tile(a);
-    if ((tile >= COMBAT_TILE_H256x64 && tile < COMBAT_TILE_G128x64) || tile == COMBAT_TILE_D256x64)
+    if ((tile >= COMBAT_TILE_H256x64 && tile < COMBAT_TILE_G128x64) || tile == COMBAT_TILE_D256x64 || tile == COMBAT_TILE_D256W64)
         return conv3x3_stats_layout(a, tile, rows, rows_per_image);
     const int gran = combat_conv_stats_granule(tile);
     if (gran <= 0) return COMBAT_EINVAL;
@@ -414,6 +416,7 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     const int tile = pick_tile(a);
     if (tile == COMBAT_TILE_C8) return conv_c8_launch(a, st);
     if (tile == COMBAT_TILE_G128x64 || tile == COMBAT_TILE_G128x32) return conv_gather_dma_launch(a, st);
+    if (tile == COMBAT_TILE_D256W64) return conv3x3_launch(a, tile, st);
     if (tile >= COMBAT_TILE_H256x64) return conv3x3_launch(a, tile, st);
     switch (tile) {
         case COMBAT_TILE_128x128: return launch<128, 128>(p, st);

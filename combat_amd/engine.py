@@ -13,6 +13,7 @@ defenses/frequency_based/model.py:49-52; their backward passes are what autograd
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -40,6 +41,7 @@ class Plan:
         self._keep: List = []
         self.marks: Dict[int, int] = {}   # call index -> flat-gradient offset complete after that call
         self.aux: set = set()             # indices of calls that may run on the auxiliary stream
+        self.wgrads: List[Tuple] = []     # (call index, WgradArgs) of the weight-gradient launches
         self._ws = None
 
     def add(self, what: str, cfunc, *args, aux: bool = False) -> None:
@@ -284,6 +286,27 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     plan.hold(a, src, dy, dw, pro, ws)
     plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a), aux=aux)
+    plan.wgrads.append((len(plan.calls) - 1, a))
+
+
+def balance_wgrads(plan: Plan, device) -> None:
+    """Weight gradients run on the auxiliary stream beside the input-gradient chain -- but they are the longer of
+    the two chains (20 launches of ~40 us against ~480 us of input gradients + norm backward in PreActResNet18's
+    backward), so the plan ended with the main stream idle behind ~400 us of queued weight gradients.  The LAST
+    `tail` weight gradients of the plan (the early layers) are therefore issued on the plan's own stream: at the
+    end of the plan both queues run weight gradients side by side (each is sized for half the chip)."""
+    tail = int(os.environ.get("COMBAT_WGRAD_MAIN_TAIL", WGRAD_MAIN_TAIL))
+    if tail <= 0 or Plan.serial:
+        return
+    aux_calls = [(ci, a) for ci, a in plan.wgrads if ci in plan.aux]
+    ws = _wgrad_workspace(device, False)
+    for ci, a in aux_calls[-tail:]:
+        plan.aux.discard(ci)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        plan.hold(ws)
+
+
+WGRAD_MAIN_TAIL = 0
 
 
 _WGRAD_WS: Dict = {}
@@ -299,7 +322,7 @@ def _wgrad_workspace(device, aux: bool = True) -> torch.Tensor:
     key = (device, bool(aux))
     ws = _WGRAD_WS.get(key)
     if ws is None:
-        ws = torch.empty((48 << 20) if aux else (16 << 20), dtype=torch.uint8, device=device)
+        ws = torch.empty(48 << 20, dtype=torch.uint8, device=device)
         _WGRAD_WS[key] = ws
     return ws
 
@@ -741,6 +764,7 @@ class PreActEngine(NetEngine):
                 P.mark(fp.offsets[pre + "bn1.weight"][0])
         rec_wgrad(P, "stem.wgrad", self.input(slot), d_out, self.stem, fp.grad_phys("conv1.weight"), aux=False)
         P.mark(0)
+        balance_wgrads(P, self.device)
         slot.plans[key] = P
         return P
 
@@ -1197,6 +1221,7 @@ class UnetEngine(NetEngine):
               d00.shape[-1], fp.grad_phys("conv0_0.bias").data_ptr(), aux=True)
         rec_wgrad(P, "conv0_0.wgrad", self.input(slot), d00, pc["conv0_0"], fp.grad_phys("conv0_0.weight"), aux=False)
         P.mark(0)
+        balance_wgrads(P, self.device)
         slot.plans["bwd"] = P
         return P
 

@@ -129,6 +129,7 @@ typedef struct combat_conv_args {
 #define COMBAT_TILE_G128x32 13
 #define COMBAT_TILE_D256x64 14   /* conv3x3_dma with 256-pixel tiles (eight waves): large layers */
 #define COMBAT_TILE_C8 15        /* 3x3 over C = 8 (c8 images, 3-channel gradients): operands straight into the MFMA registers */
+#define COMBAT_TILE_D256W64 16   /* conv3x3_dma, 256-pixel tiles as four waves of 64 pixels x 64 channels (16-wide maps, >= 16 rows) */
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);
 /* scratch bytes the launch for these args can use (0: none) */

@@ -165,6 +165,7 @@ DMA_CASES = [
     (9, 4, 512, 512, 10), (8, 4, 128, 256, 10), (3, 4, 64, 64, 10),     # eight images per tile
     (4, 32, 64, 64, 11), (3, 16, 128, 64, 11), (5, 8, 128, 64, 11), (9, 4, 512, 512, 11), (7, 4, 256, 256, 0),  # 32-channel tiles
     (3, 32, 64, 64, 14), (2, 16, 128, 128, 14), (7, 8, 128, 64, 14), (5, 8, 64, 128, 14),     # 256-pixel tiles, ragged N
+    (3, 32, 64, 64, 16), (2, 32, 128, 128, 16), (3, 16, 128, 128, 16), (5, 16, 64, 128, 16), (2, 16, 256, 64, 16),  # 64-pixel wave tiles
 ]
 
 
@@ -199,6 +200,7 @@ def test_conv3x3_dma_forward_and_dgrad(ops, n, hw, c, k, tile):
 
 @pytest.mark.parametrize("n,hw,c,k,r,stride,tile,keep_raw", [
     (4, 16, 64, 64, 3, 1, 0, True), (4, 16, 64, 128, 3, 1, 0, False),     # DMA-staged kernel
+    (4, 16, 64, 64, 3, 1, 16, True), (3, 32, 64, 128, 3, 1, 16, False),   # ... with 64-pixel wave tiles
     (4, 16, 64, 64, 3, 1, 8, False), (3, 8, 128, 128, 3, 1, 9, True),     # halo kernels
     (4, 16, 64, 128, 3, 2, 0, False), (4, 16, 8, 64, 3, 1, 0, True), (4, 16, 64, 128, 1, 2, 0, True)])  # gather kernel
 def test_conv_activation_output_and_activated_mask(ops, n, hw, c, k, r, stride, tile, keep_raw):

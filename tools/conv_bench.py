@@ -1,7 +1,8 @@
 """Per-shape convolution timings at the benchmarked batch (N = 128): every PreActResNet18 / UNet 3x3 shape, forward
 (residual + statistics or activated-output epilogue) and input gradient (mask epilogue), for the automatic tile and
-explicit tile ids.  Two numbers per case: back-to-back average (launches overlap their ramps) and an isolated launch
-bracketed by HIP events after a device sync (what a dependent chain pays).
+explicit tile ids.  Three numbers per case: back-to-back average (launches overlap their ramps), an isolated launch bracketed by HIP
+events after a device sync (what a dependent chain pays), and the same after evicting L2 / Infinity Cache (what
+the step's launches find: weights and operands come from HBM).
 
     python tools/conv_bench.py [shape-substring] [--tiles 0,10,11,12]
 """
@@ -27,6 +28,18 @@ SHAPES = [  # name, n, hw, c, k, stride
 ]
 
 
+FLUSH = None
+
+
+def flush_caches():
+    """Evict L2 and the 256 MiB Infinity Cache: the state a convolution finds in the step, where ~400 MB of other
+    tensors pass between two uses of a weight tensor."""
+    global FLUSH
+    if FLUSH is None:
+        FLUSH = torch.empty(768 << 20, dtype=torch.uint8, device="cuda")
+    FLUSH.fill_(1)
+
+
 def timeit(a, reps=30):
     for _ in range(3):
         ops.conv_launch(a)
@@ -46,7 +59,16 @@ def timeit(a, reps=30):
         e1.record()
         torch.cuda.synchronize()
         iso.append(e0.elapsed_time(e1) * 1e3)
-    return b2b, sorted(iso)[len(iso) // 2]
+    cold = []
+    for _ in range(5):
+        flush_caches()
+        torch.cuda.synchronize()
+        e0.record()
+        ops.conv_launch(a)
+        e1.record()
+        torch.cuda.synchronize()
+        cold.append(e0.elapsed_time(e1) * 1e3)
+    return b2b, sorted(iso)[len(iso) // 2], sorted(cold)[len(cold) // 2]
 
 
 def case(n, hw, c, k, stride, tile, mode, ws):
@@ -80,15 +102,15 @@ def case(n, hw, c, k, stride, tile, mode, ws):
         picked = lib.combat_conv_pick_tile(ctypes.byref(a))
         if tile and picked != tile:
             return None
-        b2b, iso = timeit(a)
-        return picked, b2b, iso
+        b2b, iso, cold = timeit(a)
+        return picked, b2b, iso, cold
     except Exception as e:   # tile not applicable to this shape
         return None
 
 
 def main():
     sel = [a for a in sys.argv[1:] if not a.startswith("--")]
-    tiles = [0, 10, 11, 12, 13, 14]
+    tiles = [0, 10, 11, 12, 13, 14, 16]
     for i, a in enumerate(sys.argv):
         if a == "--tiles":
             tiles = [int(v) for v in sys.argv[i + 1].split(",")]
@@ -102,7 +124,7 @@ def main():
             for t in tiles:
                 r = case(n, hw, c, k, stride, t, mode, ws)
                 if r is not None:
-                    cells.append("t%d[%d]: %.1f / %.1f us (%.0f TF)" % (t, r[0], r[1], r[2], gf / r[2] * 1e3))
+                    cells.append("t%d[%d]: %.1f / %.1f / cold %.1f us (%.0f TF)" % (t, r[0], r[1], r[2], r[3], gf / r[2] * 1e3))
             print("%-22s %-9s %s" % (name, mode, "  ".join(cells)), flush=True)
 
 

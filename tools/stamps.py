@@ -59,7 +59,7 @@ def run(n, hw, c, k, tile, mode=0):
         print('   max concurrent blocks on a CU (first 64 CUs): %s' % np.bincount(mx).tolist())
     st_ = (wall[:, 0] - t0) / 100.0
     print('   block start times us: p0 %.1f p25 %.1f p50 %.1f p75 %.1f p100 %.1f' % tuple(np.percentile(st_, [0, 25, 50, 75, 100])))
-for name, shape, tile in [('layer1 B128', (128, 32, 64, 64), 10), ('layer2 B128', (128, 16, 128, 128), 10), ('layer2 B256', (256, 16, 128, 128), 10),
-                    ('layer3 B128', (128, 8, 256, 256), 10), ('layer4 B256', (256, 4, 512, 512), 10)]:
+for name, shape, tile in [('layer1 B128 t10', (128, 32, 64, 64), 10), ('layer1 B128 t16', (128, 32, 64, 64), 16), ('layer2 B128 t10', (128, 16, 128, 128), 10),
+                    ('layer2 B128 t16', (128, 16, 128, 128), 16), ('layer3 B128 t11', (128, 8, 256, 256), 11), ('layer4 B128 t11', (128, 4, 512, 512), 11)]:
     print(name, flush=True)
     run(*shape, tile)
