@@ -34,7 +34,16 @@ struct W3dParams {
     int tiles_x, tiles_y, ntiles, tiles_k, tiles_c, split, per;
     unsigned x_bytes, dy_bytes;
     float *ws;   // partial-sum slabs [split][tiles_k][tiles_c][9][64][64] or null (atomics)
+    unsigned long long *stamps;   // profiling builds only (-DCOMBAT_STAMPS): cycles per phase, per workgroup
 };
+
+#ifdef COMBAT_STAMPS
+static unsigned long long *g_stamps_wgrad_host = nullptr;
+extern "C" int combat_debug_set_stamps_wgrad(void *p) { g_stamps_wgrad_host = (unsigned long long *)p; return 0; }
+#define WCLK() __builtin_readcyclecounter()
+#else
+#define WCLK() 0ull
+#endif
 
 __device__ __forceinline__ s16x4_t tr16d(const unsigned char *p) {
 #if COMBAT_EXPW == 1
@@ -112,25 +121,53 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         drel[j] = (((ti * H + ty) * W + tx) * K + k0 + chunk * 8) * 2;
         asm volatile("" : "+v"(dti[j]), "+v"(drel[j]));
     }
-    auto issue = [&](int t, auto slot_tag) __attribute__((always_inline)) {
+    // A patch's DMA = its origin (wave-uniform: image group, tile row, tile column as running counters -- the three
+    // divisions of the patch index were 300 of a patch's 2800 cycles) + NDMA pieces.
+    int nt_x, nt_y, nt_g;                                     // tile coordinates of the NEXT patch to issue
+    {
+        const int t = t_begin;
+        nt_x = t % p.tiles_x;
+        nt_y = (t / p.tiles_x) % p.tiles_y;
+        nt_g = t / (p.tiles_x * p.tiles_y);
+    }
+    int is_img0 = 0, is_oy0 = 0, is_ox0 = 0, is_xorg = 0, is_dorg = 0;
+    auto issue_prep = [&]() __attribute__((always_inline)) {  // origin of the next patch; advances the counters
+        is_img0 = nt_g * p.TI;
+        is_oy0 = nt_y * p.TH;
+        is_ox0 = nt_x * p.TW;
+        const int origin = (is_img0 * H + is_oy0) * W + is_ox0;
+        is_xorg = origin * C * 2;
+        is_dorg = origin * K * 2;
+        if (++nt_x == p.tiles_x) {
+            nt_x = 0;
+            if (++nt_y == p.tiles_y) {
+                nt_y = 0;
+                ++nt_g;
+            }
+        }
+    };
+    auto issue_piece = [&](auto j_tag, auto slot_tag) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value;
         constexpr int sbase = decltype(slot_tag)::value * stage_bytes;
-        const int tx_ = t % p.tiles_x, ty_ = (t / p.tiles_x) % p.tiles_y, ig = t / (p.tiles_x * p.tiles_y);
-        const int img0 = ig * p.TI, oy0 = ty_ * p.TH, ox0 = tx_ * p.TW;
-        const int origin = (img0 * H + oy0) * W + ox0;        // wave-uniform
-        const int xorg = origin * C * 2, dorg = origin * K * 2;
-#pragma unroll
-        for (int j = 0; j < 1; ++j) {
-            const unsigned off = img0 + dti[j] < a.N ? (unsigned)(dorg + drel[j]) : kOob;
+        if constexpr (j == 0) {
+            const unsigned off = is_img0 + dti[0] < a.N ? (unsigned)(is_dorg + drel[0]) : kOob;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(dyrsrc, (lds_void_t *)(smem + sbase + wid * 1024), 16, off, 0, 0, 0);
+        } else if constexpr (j <= HPW) {
+            const int d = hdec[j - 1];
+            const bool ok = d >= 0 && is_img0 + (d >> 16) < a.N && (unsigned)(is_oy0 + ((d >> 8) & 255) - 1) < (unsigned)H &&
+                            (unsigned)(is_ox0 + (d & 255) - 1) < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(is_xorg + hrel[j - 1]) : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void_t *)(smem + sbase + 8192 + (wid + 8 * (j - 1)) * 1024), 16, off, 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < HPW; ++j) {
-            const int d = hdec[j];
-            const bool ok = d >= 0 && img0 + (d >> 16) < a.N && (unsigned)(oy0 + ((d >> 8) & 255) - 1) < (unsigned)H &&
-                            (unsigned)(ox0 + (d & 255) - 1) < (unsigned)W;
-            const unsigned off = ok ? (unsigned)(xorg + hrel[j]) : kOob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void_t *)(smem + sbase + 8192 + (wid + 8 * j) * 1024), 16, off, 0, 0, 0);
-        }
+    };
+    auto issue = [&](auto slot_tag) __attribute__((always_inline)) {   // a whole patch at once (the first NS - 1)
+        using std::integral_constant;
+        issue_prep();
+        issue_piece(integral_constant<int, 0>{}, slot_tag);
+        issue_piece(integral_constant<int, 1>{}, slot_tag);
+        issue_piece(integral_constant<int, 2>{}, slot_tag);
+        issue_piece(integral_constant<int, 3>{}, slot_tag);
+        issue_piece(integral_constant<int, 4>{}, slot_tag);
     };
 
     // ---- per-lane fragment addresses (relative to the stage).  Transposing read: lane 4q+pp of a
@@ -180,15 +217,24 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
                 acc[tap][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[ks][i], fx[ks], acc[tap][i], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto compute = [&](auto slot_tag) __attribute__((always_inline)) {
+    auto compute = [&](auto slot_tag, auto nslot_tag, bool ahead) __attribute__((always_inline)) {
         const unsigned char *st = smem + decltype(slot_tag)::value * stage_bytes;   // folds into the reads' immediates
-        bf16x8_t fk[2][2], fx0[2], fx1[2];
+        bf16x8_t fk[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 fk[ks][i] = join8(tr16d(st + (dya[ks][0] ^ (i * 64))), tr16d(st + (dya[ks][1] ^ (i * 64))));
         using std::integral_constant;
+        // tap t: fragments of tap t + 1 -> other register set | MFMAs of tap t
+        // (tried: one DMA piece of patch i + NS - 1 behind every second tap block instead of all of them in front of
+        // the patch -- in-kernel stamps: compute 1452 -> 2513 cycles per patch for 524 cycles of issue removed, a DMA
+        // issue between two MFMA blocks stalls both waves of the SIMD; fragments three taps ahead instead of one --
+        // compute 1506 -> 1420, but the 24 extra registers made the compiler re-derive the DMA offsets per patch:
+        // issue 408 -> 2576)
+        (void)nslot_tag;
+        (void)ahead;
+        bf16x8_t fx0[2], fx1[2];
         x_frags(fx0, st, integral_constant<int, 0>{});
 #define COMBAT_W3_TAP(t, cur, nxt)                                                   \
         if (t < 8) x_frags(nxt, st, integral_constant<int, (t < 8 ? t + 1 : 8)>{});  \
@@ -198,6 +244,7 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         COMBAT_W3_TAP(8, fx0, fx1)
 #undef COMBAT_W3_TAP
     };
+    static_assert(HPW <= 4, "issue() spells out 1 + HPW <= 5 pieces");
 
     // ---- ring of NS stages: patch i of this workgroup lives in slot i % NS; NS - 1 patches are DMA'd
     // ahead.  The loop is unrolled over the slots so that every LDS address is "register + immediate".
@@ -206,15 +253,27 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     // everything younger (NS - 2 patches) may stay in flight.
     const int npatch = t_end - t_begin;
     using std::integral_constant;
-    issue(t_begin, integral_constant<int, 0>{});
-    if (NS > 2 && npatch > 1) issue(t_begin + 1, integral_constant<int, 1 % NS>{});
+    issue(integral_constant<int, 0>{});
+    if (NS > 2 && npatch > 1) issue(integral_constant<int, 1 % NS>{});
     if (NS > 2 && npatch > 1) wait_vm_lgkm0_barrier<NDMA>(); else wait_vm_lgkm0_barrier<0>();
+    unsigned long long ph[4] = {0, 0, 0, 0};
+    const unsigned long long c_loop0 = WCLK();
     auto body = [&](auto slot_tag, int i) __attribute__((always_inline)) {
         constexpr int slot = decltype(slot_tag)::value, nslot = (slot + NS - 1) % NS;
         const bool ahead = i + NS - 1 < npatch;
-        if (ahead) issue(t_begin + i + NS - 1, integral_constant<int, nslot>{});
-        compute(integral_constant<int, slot>{});
+        const unsigned long long c0 = WCLK();
+        if (ahead) issue(integral_constant<int, nslot>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long c1 = WCLK();
+        compute(integral_constant<int, slot>{}, integral_constant<int, nslot>{}, ahead);
+        const unsigned long long c2 = WCLK();
         if (ahead) wait_vm_lgkm0_barrier<(NS - 2) * NDMA>(); else wait_vm_lgkm0_barrier<0>();
+#ifdef COMBAT_STAMPS
+        const unsigned long long c3 = WCLK();
+        ph[0] += c1 - c0; ph[1] += c2 - c1; ph[2] += c3 - c2; ph[3] += 1;
+#else
+        (void)c0; (void)c1; (void)c2;
+#endif
     };
     for (int i = 0; i < npatch; i += NS) {
         body(integral_constant<int, 0>{}, i);
@@ -222,63 +281,78 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         if (NS > 2 && i + 2 < npatch) body(integral_constant<int, 2 % NS>{}, i + 2);
     }
     static_assert(NS == 2 || NS == 3, "the patch loop is unrolled for rings of two or three stages");
+#ifdef COMBAT_STAMPS
+    const unsigned long long c_loop1 = WCLK();
+#endif
 
-    // ---- nine [64 n][64 c] partials -> fp32 LDS image -> atomics in 256-byte runs along c
-    float *ep = reinterpret_cast<float *>(smem);
-    constexpr int EPS = 68;
-    const int fr = lane & 15;
+    // ---- nine [64 n][64 c] partials.  With a workspace: this workgroup's slab in FRAGMENT order -- per tap
+    // [dy fragment i][wave][lane] x 4 floats, i.e. every accumulator register quad as one 16-byte store, 1 KB per
+    // wave instruction, no LDS pass and no barrier (the row-major form cost 9 x (LDS image + two barriers) = 9.5 k of a
+    // workgroup's 57 k cycles); wgrad3x3_reduce_kernel maps a quad back to its (row, column).
+    if (p.ws) {
+        float *slab = p.ws + (size_t)blockIdx.x * 9 * 4096;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                *reinterpret_cast<f32x4_t *>(slab + tap * 4096 + ((i * 8 + wid) * 64 + lane) * 4) = acc[tap][i];
+    } else {
+        // without one: fp32 LDS image per tap -> atomics in 256-byte runs along c
+        float *ep = reinterpret_cast<float *>(smem);
+        constexpr int EPS = 68;
+        const int fr = lane & 15;
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < 9; ++tap) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int col = wave_c * 16 + fr;
-            const int row = (i * 2 + wave_k) * 16 + fq * 4;
-            f32x4_t v;
-            switch (tap) {   // acc is indexed statically (a runtime index would put it in scratch)
-                case 0: v = acc[0][i]; break;
-                case 1: v = acc[1][i]; break;
-                case 2: v = acc[2][i]; break;
-                case 3: v = acc[3][i]; break;
-                case 4: v = acc[4][i]; break;
-                case 5: v = acc[5][i]; break;
-                case 6: v = acc[6][i]; break;
-                case 7: v = acc[7][i]; break;
-                default: v = acc[8][i]; break;
-            }
+            for (int i = 0; i < 2; ++i) {
+                const int col = wave_c * 16 + fr;
+                const int row = (i * 2 + wave_k) * 16 + fq * 4;
+                f32x4_t v;
+                switch (tap) {   // acc is indexed statically (a runtime index would put it in scratch)
+                    case 0: v = acc[0][i]; break;
+                    case 1: v = acc[1][i]; break;
+                    case 2: v = acc[2][i]; break;
+                    case 3: v = acc[3][i]; break;
+                    case 4: v = acc[4][i]; break;
+                    case 5: v = acc[5][i]; break;
+                    case 6: v = acc[6][i]; break;
+                    case 7: v = acc[7][i]; break;
+                    default: v = acc[8][i]; break;
+                }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) ep[(row + e) * EPS + col] = v[e];
-        }
-        __syncthreads();
-        if (p.ws) {   // this workgroup's slab: plain 16-byte stores, combined by wgrad3x3_reduce_kernel
-            float *slab = p.ws + ((size_t)blockIdx.x * 9 + tap) * 4096;
-            for (int idx = tid; idx < 64 * 16; idx += 512) {
-                const int row = idx >> 4, c4 = (idx & 15) * 4;
-                const float *e = ep + row * EPS + c4;
-                *reinterpret_cast<f32x4_t *>(slab + row * 64 + c4) = f32x4_t{e[0], e[1], e[2], e[3]};
+                for (int e = 0; e < 4; ++e) ep[(row + e) * EPS + col] = v[e];
             }
-        } else {
+            __syncthreads();
             for (int idx = tid; idx < 64 * 64; idx += 512) {
                 const int row = idx >> 6, col = idx & 63;
                 const int n = k0 + row, c = c0 + col;
                 if (n < a.k_real && c < a.c_real) atomicAdd(a.dw + ((size_t)n * 9 + tap) * a.c_real + c, ep[row * EPS + col]);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
+#ifdef COMBAT_STAMPS
+    if (tid == 0 && p.stamps) {
+        unsigned long long *o = p.stamps + blockIdx.x * 8;
+        o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = ph[3];
+        o[4] = c_loop1 - c_loop0; o[5] = WCLK() - c_loop1; o[6] = c_loop0;
+    }
+#endif
 }
 
-// dw += sum over the pixel ranges' slabs.  grid.x: 4-element groups of the [tiles][9][64][64] partial
-// tile space (256 threads each), grid.y: groups of ranges (each adds its share with one fp32 atomic
-// per element -- a few per element instead of `split`).
+// dw += sum over the pixel ranges' slabs.  grid.x: register quads of the [tiles][9][1024] partial tile space in the
+// kernel's fragment order (256 threads each), grid.y: groups of ranges (each adds its share with one fp32 atomic
+// per element -- a few per element instead of `split`).  Quad f4 of a tap = [dy fragment i][wave][lane]:
+// rows (i * 2 + (wave & 1)) * 16 + (lane >> 4) * 4 + 0..3 of column (wave >> 1) * 16 + (lane & 15).
 __global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw,
                                                               int base, int tiles_c, int split, int k_real, int c_real) {
-    const long e4 = (long)blockIdx.x * 256 + threadIdx.x;          // float4 index inside [base][9][64][16]
+    const long e4 = (long)blockIdx.x * 256 + threadIdx.x;          // quad index inside [base][9][1024]
     if (e4 >= (long)base * 9 * 1024) return;
-    const int c4 = (int)(e4 & 15) * 4, row = (int)(e4 >> 4) & 63, tap = (int)((e4 >> 10) % 9), tile = (int)(e4 / (9 * 1024));
+    const int f4 = (int)(e4 & 1023), tap = (int)((e4 >> 10) % 9), tile = (int)(e4 / (9 * 1024));
     const int per = (split + gridDim.y - 1) / gridDim.y;
     const int s0 = blockIdx.y * per, s1 = s0 + per < split ? s0 + per : split;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const float *src = ws + ((size_t)tile * 9 + tap) * 4096 + row * 64 + c4;
+    const float *src = ws + ((size_t)tile * 9 + tap) * 4096 + f4 * 4;
     const size_t sstride = (size_t)base * 9 * 4096;
     int s = s0;
     for (; s + 4 <= s1; s += 4) {   // four independent loads in flight
@@ -289,16 +363,17 @@ __global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float *__res
         acc += (v0 + v1) + (v2 + v3);
     }
     for (; s < s1; ++s) acc += *reinterpret_cast<const f32x4_t *>(src + (size_t)s * sstride);
+    const int i = f4 >> 9, wave = (f4 >> 6) & 7, lane = f4 & 63;
+    const int row = (i * 2 + (wave & 1)) * 16 + (lane >> 4) * 4, col = (wave >> 1) * 16 + (lane & 15);
     const int tile_c = tile % tiles_c, tile_k = tile / tiles_c;
-    const int n = tile_k * 64 + row, c = tile_c * 64 + c4;
-    if (n < k_real && s0 < s1) {
-        float *o = dw + ((size_t)n * 9 + tap) * c_real + c;
-        if (gridDim.y == 1 && c + 3 < c_real) {   // sole owner of these elements: no atomics
-            *reinterpret_cast<f32x4_t *>(o) += acc;
-        } else {
+    const int n = tile_k * 64 + row, c = tile_c * 64 + col;
+    if (c < c_real && s0 < s1) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (c + e < c_real) atomicAdd(o + e, acc[e]);
+        for (int e = 0; e < 4; ++e) {
+            if (n + e >= k_real) break;
+            float *o = dw + ((size_t)(n + e) * 9 + tap) * c_real + c;
+            if (gridDim.y == 1) *o += acc[e];     // sole owner of these elements: no atomics
+            else atomicAdd(o, acc[e]);
         }
     }
 }
@@ -391,6 +466,11 @@ int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st) {
     const bool use_ws = split > 1 && a->workspace && a->workspace_bytes >= (long)split * base * 9 * 4096 * 4;
     if (!use_ws) split = pick_split(a, p, false);
     p.ws = use_ws ? reinterpret_cast<float *>(a->workspace) : nullptr;
+#ifdef COMBAT_STAMPS
+    p.stamps = g_stamps_wgrad_host;
+#else
+    p.stamps = nullptr;
+#endif
     p.per = (p.ntiles + split - 1) / split;
     p.split = (p.ntiles + p.per - 1) / p.per;
     const int blocks = base * p.split;
