@@ -358,21 +358,39 @@ __global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs 
         load8f(a.add_scale + c, asc);
         load8f(a.add_shift + c, ash);
     }
-    for (long i = i0 + pl; i < i1; i += 32) {
-        const long off = ((long)g * a.pxg + i) * a.C + c;
-        float v[8];
-        unpack8(*reinterpret_cast<const uint4 *>(a.x + off), v);
+    // Eight pixels per thread and pass, ALL their loads issued before the first is consumed: written as a plain
+    // load -> arithmetic -> store loop every iteration waited out its own load (x and act may alias for all the
+    // compiler knows, so it keeps the order) -- eight exposed round trips to HBM per thread for a 256-pixel chunk,
+    // most of the launch's 10 us.
+    constexpr int NB = 8;
+    for (long ib = i0 + pl; ib < i1; ib += 32 * NB) {
+        u32x4_t lx[NB], la[NB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
-        if (a.add) {
-            float r[8];
-            unpack8(*reinterpret_cast<const uint4 *>(a.add + off), r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += fmaf(r[e], asc[e], ash[e]);
+        for (int q = 0; q < NB; ++q) {
+            const long i = ib + 32 * q;
+            const long off = ((long)g * a.pxg + (i < i1 ? i : i1 - 1)) * a.C + c;
+            lx[q] = *reinterpret_cast<const u32x4_t *>(a.x + off);
+            if (a.add) la[q] = *reinterpret_cast<const u32x4_t *>(a.add + off);
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
-        *reinterpret_cast<uint4 *>(a.act + off) = pack8(v);
+        for (int q = 0; q < NB; ++q) {
+            const long i = ib + 32 * q;
+            if (i >= i1) break;
+            const long off = ((long)g * a.pxg + i) * a.C + c;
+            float v[8];
+            unpack8v(lx[q], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+            if (a.add) {
+                float r[8];
+                unpack8v(la[q], r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += fmaf(r[e], asc[e], ash[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+            *reinterpret_cast<u32x4_t *>(a.act + off) = pack8v(v);
+        }
     }
 }
 
@@ -468,20 +486,35 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const FusedBwdArgs 
     const long i0 = (long)chunk * a.chunk_px;
     long i1 = i0 + a.chunk_px;
     if (i1 > a.pxg) i1 = a.pxg;
-    for (long i = i0 + pl; i < i1; i += 32) {
-        const long off = ((long)g * a.pxg + i) * a.C + c;
-        float dv[8], xv[8], o[8];
-        unpack8(*reinterpret_cast<const uint4 *>(a.dz + off), dv);
-        unpack8(*reinterpret_cast<const uint4 *>(a.x + off), xv);
+    constexpr int NB = 8;   // (all of a pass's loads before its first use: see norm_act_fused_kernel)
+    for (long ib = i0 + pl; ib < i1; ib += 32 * NB) {
+        u32x4_t ld[NB], lx[NB], la[NB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaf(ka[e], dv[e], fmaf(kb[e], xv[e], kc[e]));
-        if (a.add) {
-            float ad[8];
-            unpack8(*reinterpret_cast<const uint4 *>(a.add + off), ad);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += ad[e];
+        for (int q = 0; q < NB; ++q) {
+            const long i = ib + 32 * q;
+            const long off = ((long)g * a.pxg + (i < i1 ? i : i1 - 1)) * a.C + c;
+            ld[q] = *reinterpret_cast<const u32x4_t *>(a.dz + off);
+            lx[q] = *reinterpret_cast<const u32x4_t *>(a.x + off);
+            if (a.add) la[q] = *reinterpret_cast<const u32x4_t *>(a.add + off);
         }
-        *reinterpret_cast<uint4 *>(a.dx + off) = pack8(o);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const long i = ib + 32 * q;
+            if (i >= i1) break;
+            const long off = ((long)g * a.pxg + i) * a.C + c;
+            float dv[8], xv[8], o[8];
+            unpack8v(ld[q], dv);
+            unpack8v(lx[q], xv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(ka[e], dv[e], fmaf(kb[e], xv[e], kc[e]));
+            if (a.add) {
+                float ad[8];
+                unpack8v(la[q], ad);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += ad[e];
+            }
+            *reinterpret_cast<u32x4_t *>(a.dx + off) = pack8v(o);
+        }
     }
 }
 
