@@ -121,6 +121,13 @@ SIGNATURES = {
     "combat_affine_act": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),
     "combat_dct_u8": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "combat_linear_nhwc": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "combat_grid_head_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "combat_wanet_grid": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "combat_warp_fwd": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_warp_bwd": (C.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_warp_bwd_input": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "combat_wanet_field_bwd": (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                         c_vp, c_vp, c_vp, c_vp]),
 }
 
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x16, TILE_64x128 = 1, 2, 3, 4, 5

@@ -25,6 +25,13 @@ def create_backdoor(netG, inputs: torch.Tensor, opt, sigma: float = None) -> tor
     eng = netG._net_engine()
     eng.refresh()
     inputs = inputs.contiguous().float()
+    if netG.arch == "gridgen":   # WaNet: warp by the generator's field (train_generator_wanet.py:151-157, :346-352)
+        from ._lib import lib
+        g = eng.forward_grid(hw, float(opt.grid_rescale))
+        out = torch.empty_like(inputs)
+        ops.check(lib.combat_warp_fwd(inputs.data_ptr(), None, g["grid"].data_ptr(), 0, n, hw, out.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream), "combat_warp_fwd")
+        return out
     from .engine import pad_batch
     slot = eng.slot("api", pad_batch(n), hw)
     ops.image_to_c8(inputs, eng.input(slot))

@@ -1227,6 +1227,72 @@ class UnetEngine(NetEngine):
 
 
 # --------------------------------------------------------------------------------------------
+# WaNet grid generator
+# --------------------------------------------------------------------------------------------
+
+
+class GridEngine(NetEngine):
+    """GridGenerator (networks/models.py:344-385) + the warp of train_generator_wanet.py:151-157.
+
+    The reference pools an affine-free InstanceNorm output -- spatial mean exactly 0 -- so the network's output
+    is tanh(fc2(lrelu(fc1.bias))) for every input and its encoder receives no gradient (pinned against the
+    reference module: tests/test_oracle_golden.py::test_grid_generator_is_a_constant_field...).  The engine
+    therefore computes the [2][S][S] field from the three head tensors, the [H][H][2] sampling grid shared by the
+    batch, and in the backward the gradients of fc1.bias, fc2.weight and fc2.bias; every other parameter keeps a
+    zero gradient (weight decay still applies in the optimiser, as in the reference)."""
+
+    def __init__(self, module):
+        super().__init__(module)
+        m = module
+        self.S, self.nf = int(m.S), int(m.fc1.out_features)
+        self.nout = 2 * self.S * self.S
+        self.field = torch.zeros(self.nout, dtype=f32, device=self.device)
+        self._grids: Dict[int, dict] = {}
+
+    def refresh(self) -> None:   # no packed operands
+        self.weights_dirty = False
+
+    def grid_bufs(self, hw: int) -> dict:
+        g = self._grids.get(hw)
+        if g is None:
+            # U[H][S]: the linear map of F.upsample(size=H, mode="bicubic", align_corners=True) along one axis
+            # (train_generator_wanet.py:152), taken from the operator itself on the basis vectors
+            eye = torch.eye(self.S, dtype=f32).view(self.S, 1, self.S, 1)
+            u = torch.nn.functional.interpolate(eye, size=(hw, 1), mode="bicubic", align_corners=True)   # [S,1,H,1]
+            U = u[:, 0, :, 0].t().contiguous()
+            g = dict(U=U.to(self.device), noise_grid=torch.zeros(hw, hw, 2, dtype=f32, device=self.device),
+                     grid=torch.zeros(hw, hw, 2, dtype=f32, device=self.device))
+            self._grids[hw] = g
+        return g
+
+    def _head(self):
+        fp = self.fp
+        return (fp._slice(fp.flat, "fc1.bias"), fp._slice(fp.flat, "fc2.weight"), fp._slice(fp.flat, "fc2.bias"))
+
+    def forward_grid(self, hw: int, rescale: float, st=None) -> dict:
+        """field, noise_grid and the sampling grid for H = hw (two launches)."""
+        st = torch.cuda.current_stream().cuda_stream if st is None else st
+        g = self.grid_bufs(hw)
+        b1, w2, b2 = self._head()
+        ops.check(lib.combat_grid_head_fwd(b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), self.nf, self.nout,
+                                           self.field.data_ptr(), st), "combat_grid_head_fwd")
+        ops.check(lib.combat_wanet_grid(self.field.data_ptr(), g["U"].data_ptr(), self.S, hw, float(rescale),
+                                        g["noise_grid"].data_ptr(), g["grid"].data_ptr(), st), "combat_wanet_grid")
+        return g
+
+    def backward_field(self, partial: torch.Tensor, groups: int, hw: int, rescale: float, l2_scale: float, st=None) -> None:
+        """d(loss)/d(grid) partial sums -> gradients of the head in fp.grad (the rest of fp.grad must be zero)."""
+        st = torch.cuda.current_stream().cuda_stream if st is None else st
+        g, fp = self.grid_bufs(hw), self.fp
+        b1, w2, _ = self._head()
+        ops.check(lib.combat_wanet_field_bwd(partial.data_ptr(), groups, g["noise_grid"].data_ptr(), g["U"].data_ptr(), self.S, hw,
+                                             float(rescale), float(l2_scale), self.field.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                             self.nf, fp._slice(fp.grad, "fc1.bias").data_ptr(),
+                                             fp._slice(fp.grad, "fc2.weight").data_ptr(),
+                                             fp._slice(fp.grad, "fc2.bias").data_ptr(), None, st), "combat_wanet_field_bwd")
+
+
+# --------------------------------------------------------------------------------------------
 # Frequency detector (metric only)
 # --------------------------------------------------------------------------------------------
 
@@ -1283,7 +1349,8 @@ class FreqEngine(NetEngine):
 # drop-in module(x) with autograd (reference call signature; not the fast path)
 # --------------------------------------------------------------------------------------------
 
-ENGINES = {"preact_resnet18": PreActEngine, "resnet18": ResNetEngine, "unet": UnetEngine, "freq": FreqEngine}
+ENGINES = {"preact_resnet18": PreActEngine, "resnet18": ResNetEngine, "unet": UnetEngine, "freq": FreqEngine,
+           "gridgen": GridEngine}
 
 
 def build_engine(module) -> NetEngine:
@@ -1358,6 +1425,13 @@ def module_forward(module, x: torch.Tensor) -> torch.Tensor:
         return _GeneratorFn.apply(module, x, *params)
     if module.arch in ("preact_resnet18", "resnet18"):
         return _ClassifierFn.apply(module, x, *params)
+    if module.arch == "gridgen":     # [B, 2, S, S]: the same field for every sample (see GridEngine)
+        eng = module._net_engine()
+        st = torch.cuda.current_stream().cuda_stream
+        b1, w2, b2 = eng._head()
+        ops.check(lib.combat_grid_head_fwd(b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), eng.nf, eng.nout,
+                                           eng.field.data_ptr(), st), "combat_grid_head_fwd")
+        return eng.field.view(1, 2, eng.S, eng.S).expand(x.shape[0], -1, -1, -1).clone()
     if module.arch == "freq":
         eng = module._net_engine()
         eng.refresh()

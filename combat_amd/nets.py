@@ -8,7 +8,7 @@ which fails loudly when the gfx950 library is missing.
 
 Mirrored interfaces:
   UnetGenerator     networks/models.py:268-341
-  GridGenerator     networks/models.py:344-385   (parameters only this round)
+  GridGenerator     networks/models.py:344-385
   PreActResNet18    classifier_models/preact_resnet.py:13-40, 72-110
   ResNet18          classifier_models/resnet.py:15-37, 68-106
   FrequencyModel    defenses/frequency_based/model.py:8-52
@@ -91,9 +91,6 @@ class GridGenerator(_HipModule):
             setattr(self, name, nn.Conv2d(cin, nf * co, kernel_size=3, stride=stride, padding=1, bias=use_bias))
         self.fc1 = nn.Linear(nf * 8, nf)
         self.fc2 = nn.Linear(nf, self.S * self.S * 2)
-
-    def forward(self, x):
-        raise NotImplementedError("GridGenerator (WaNet, BASELINE config 5) is a later SURVEY section-8 row")
 
 
 class _PreActBlock(nn.Module):
@@ -179,12 +176,16 @@ class FrequencyModel(_HipModule):
 
 def configure_dataset(opt) -> None:
     """Input dimensions / class count per dataset, as every entry script's main() sets them
-    (train_generator.py:470-486).  imagenet10 (224 x 224, WaNet) is a later SURVEY section-8(f) row."""
+    (train_generator.py:470-486; imagenet10: train_generator_wanet.py:472-477 -- 224 x 224, 10 classes, bs 32)."""
     if opt.dataset == "cifar10":
         opt.input_height, opt.input_width, opt.input_channel = 32, 32, 3
     elif opt.dataset == "celeba":
         opt.input_height, opt.input_width, opt.input_channel = 64, 64, 3
         opt.num_classes = 8
+    elif opt.dataset == "imagenet10":
+        opt.input_height, opt.input_width, opt.input_channel = 224, 224, 3
+        opt.num_classes = 10
+        opt.bs = 32
     else:
         raise Exception("Invalid Dataset")
 
@@ -198,4 +199,6 @@ def default_classifier(opt):
         return PreActResNet18()
     if opt.dataset == "celeba":
         return ResNet18(num_classes=opt.num_classes)
-    raise Exception("dataset %r is a later SURVEY section-8 row; the HIP path covers cifar10 and celeba" % opt.dataset)
+    if opt.dataset == "imagenet10":   # train_generator_wanet.py:72-74 (the reference's scaler table lacks 224: SURVEY D4)
+        return ResNet18(num_classes=opt.num_classes, input_size=opt.input_height)
+    raise Exception("Invalid Dataset")

@@ -180,7 +180,7 @@ class AlternatedStep:
         self.sC_eval = eC.slot("C.evalbd", n, hw)      # netC on the triggered images: on the critical path, so on its own
         self.sC_met = eC.slot("C.metric", n, hw)       # netC on the clean images (accuracy only): second stream
         self.sK_eval = eK.slot("K.eval2", 2 * n, hw)
-        self.sG = eG.slot("G", n, hw)
+        self.sG = self._gen_slot(n)
         self.sF = self.eF.slot("F", n, hw) if self.eF is not None else None
         # the heads read their labels straight out of the step table (bound before the plans marshal pointers)
         lab = self.d_targets
@@ -192,14 +192,20 @@ class AlternatedStep:
             C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False),
             C_met_f=eC.forward_plan(self.sC_met, False, 1.0, False),
             K_eval_f=eK.forward_plan(self.sK_eval, False, w_cm, True, split_head=True),
-            G_f=eG.forward_plan(self.sG), G_b=eG.backward_plan(self.sG),
         )
+        self.pl.update(self._gen_plans())
         self.sC_bd = self.sC_eval
         self.sK_bd = self.sK_eval.half_view(n, n, eK.FWD_SHARED)
         self.pl["C_bd_b"] = eC.backward_eval_plan(self.sC_bd, 1.0)
         self.pl["K_bd_b"] = eK.backward_eval_plan(self.sK_bd, w_cm)
         if self.sF is not None:
             self.pl["F_f"] = self.eF.forward_plan(self.sF)
+
+    def _gen_slot(self, n):
+        return self.eG.slot("G", n, self.hw)
+
+    def _gen_plans(self) -> dict:
+        return dict(G_f=self.eG.forward_plan(self.sG), G_b=self.eG.backward_plan(self.sG))
 
     @staticmethod
     def _table_bytes(n: int) -> int:
@@ -232,7 +238,7 @@ class AlternatedStep:
         targets_cpu = targets_cpu.cpu()
         bd_targets_cpu = create_targets_bd(targets_cpu, opt).cpu()
         if rnd is None:
-            rnd = draw_randomness(targets_cpu, bd_targets_cpu, opt, self.transforms, getattr(opt, "sigma", (0.1, 1.0)))
+            rnd = self._draw(targets_cpu, bd_targets_cpu)
         nb = rnd.num_bd
         # ---- host tables (train_generator.py:181-204: batch order [poisoned, rest of target class, others])
         perm, tot, idx_small, idx_total = poison_tables(targets_cpu, bd_targets_cpu, nb)
@@ -263,24 +269,20 @@ class AlternatedStep:
         eC, eG, eK, eF, pl = self.eC, self.eG, self.eK, self.eF, self.pl
         for e in (eC, eG, eK) + ((eF,) if eF is not None else ()):
             e.refresh()
-        P_, k1c, k1g = self.P.data_ptr(), self.k1[0].data_ptr(), self.k1[1].data_ptr()
-        rate = float(opt.noise_rate)
+        k1c, k1g = self.k1[0].data_ptr(), self.k1[1].data_ptr()
         x_ptr = self.inputs.data_ptr()
 
         # ---- generator forward of the whole batch, ONCE for both phases.  The reference runs netG twice
         # (train_generator.py:187 on the poisoned images in eval mode, :216 on the batch in train mode);
         # the UNet has InstanceNorm without running statistics and no dropout, and its weights only
         # change at the end of Phase G, so the first call's outputs are rows of the second's.
-        ops.check(lib.combat_image_to_c8(x_ptr, n, hw, eG.input(self.sG).data_ptr(), st), "c8 G")
-        pl["G_f"].run(prof)
-        noise = eG.output(self.sG)
+        self._gen_forward(x_ptr, n, st, prof)
         ev_fork = torch.cuda.Event()           # what the second stream's chain depends on (see the fork below)
         ev_fork.record()
 
         # ================= Phase C (train_generator.py:175-212) =================
         if nb:   # the poisoned images: rows index_small[:nb] of the batch and of the generator output (:186-194)
-            ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1c, rate, nb, hw, self.tab_i[0].data_ptr(),
-                                             self.cat_src[n:].data_ptr(), None, None, st), "trigger C")
+            self._trigger_c(x_ptr, nb, k1c, st)
         ops.check(lib.combat_augment_fwd(self.cat_src.data_ptr(), self.tab_i[1].data_ptr(), aug_ptr[0], n, hw,
                                          eC.input(self.sC_train).data_ptr(), None, st), "augment 0")
         pl["C_train_f"].run(prof)
@@ -297,8 +299,7 @@ class AlternatedStep:
         bd_ptr = self.bd.data_ptr()
         with torch.cuda.stream(side):
             s2 = side.cuda_stream
-            ops.check(lib.combat_trigger_fwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, None, bd_ptr, None,
-                                             self.mse.data_ptr(), s2), "trigger G")            # :224-226
+            self._trigger_g(x_ptr, n, k1g, s2)                                                    # :224-226
             ev_bd = torch.cuda.Event()
             ev_bd.record()
             ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[1], n, hw, xK.data_ptr(), None, s2), "augment 1")  # :214
@@ -340,16 +341,11 @@ class AlternatedStep:
                 ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), s2), "dct")
                 pl["F_f"].run(prof)
                 self.acc_side += (self.sF.bufs["logits"].argmax(1) == 1).sum()
-            self.acc[0] += self.mse.sum() / float(n * 3 * hw * hw)
-            self.acc[1] += self._grad_l2(self.inputs, self.bd)
+            self._log_l2_terms(n)
             ev_met = torch.cuda.Event()
             ev_met.record()
         torch.cuda.current_stream().wait_event(ev_side)     # ---- join
-        l2_scale = float(opt.L2_weight) / float(n * 3 * hw * hw)          # :234, :253
-        ops.check(lib.combat_trigger_bwd(x_ptr, noise.data_ptr(), P_, k1g, rate, n, hw, self.d_bd.data_ptr(),
-                                         self.d_bd2.data_ptr(), bd_ptr, l2_scale, 1,
-                                         self.sG.buf("g.z", (n, hw, hw, 8)).data_ptr(), st), "trigger bwd")   # d_bd + d_bd2
-        self._backward_allreduce(pl["G_b"], eG, prof)
+        self._gen_backward(x_ptr, n, k1g, st, prof)
         eG.fp.sgd_step(float(lr_g if lr_g is not None else opt.lr_G), grad_scale=1.0 / self.world)
         if not self.keep_grads:
             eG.fp.zero_grad_behind()
@@ -358,6 +354,39 @@ class AlternatedStep:
         torch.cuda.current_stream().wait_event(ev_met)
         self.samples += n
         self.steps_done += 1
+
+    # ------------------------------------------------------------------ trigger-specific pieces (UNet + low-pass / clamp-mix / blur)
+    def _draw(self, targets_cpu, bd_targets_cpu) -> StepRandomness:
+        return draw_randomness(targets_cpu, bd_targets_cpu, self.opt, self.transforms, getattr(self.opt, "sigma", (0.1, 1.0)))
+
+    def _gen_forward(self, x_ptr, n, st, prof) -> None:
+        ops.check(lib.combat_image_to_c8(x_ptr, n, self.hw, self.eG.input(self.sG).data_ptr(), st), "c8 G")
+        self.pl["G_f"].run(prof)
+
+    def _trigger_c(self, x_ptr, nb, k1c, st) -> None:
+        """Poisoned images of Phase C -> cat_src[n:] (train_generator.py:186-194)."""
+        ops.check(lib.combat_trigger_fwd(x_ptr, self.eG.output(self.sG).data_ptr(), self.P.data_ptr(), k1c, float(self.opt.noise_rate),
+                                         nb, self.hw, self.tab_i[0].data_ptr(), self.cat_src[self.N:].data_ptr(), None, None, st),
+                  "trigger C")
+
+    def _trigger_g(self, x_ptr, n, k1g, s2) -> None:
+        """Triggered copy of the whole batch -> self.bd (+ per-plane squared error) (train_generator.py:224-226)."""
+        ops.check(lib.combat_trigger_fwd(x_ptr, self.eG.output(self.sG).data_ptr(), self.P.data_ptr(), k1g, float(self.opt.noise_rate),
+                                         n, self.hw, None, self.bd.data_ptr(), None, self.mse.data_ptr(), s2), "trigger G")
+
+    def _log_l2_terms(self, n) -> None:
+        """loss_l2 / loss_grad_l2 running sums (train_generator.py:234-243; the second is logged only)."""
+        self.acc[0] += self.mse.sum() / float(n * 3 * self.hw * self.hw)
+        self.acc[1] += self._grad_l2(self.inputs, self.bd)
+
+    def _gen_backward(self, x_ptr, n, k1g, st, prof) -> None:
+        """Image gradient (d_bd + d_bd2) + the L2 term -> generator parameter gradients (train_generator.py:253-254)."""
+        hw = self.hw
+        l2_scale = float(self.opt.L2_weight) / float(n * 3 * hw * hw)          # :234, :253
+        ops.check(lib.combat_trigger_bwd(x_ptr, self.eG.output(self.sG).data_ptr(), self.P.data_ptr(), k1g, float(self.opt.noise_rate),
+                                         n, hw, self.d_bd.data_ptr(), self.d_bd2.data_ptr(), self.bd.data_ptr(), l2_scale, 1,
+                                         self.sG.buf("g.z", (n, hw, hw, 8)).data_ptr(), st), "trigger bwd")   # d_bd + d_bd2
+        self._backward_allreduce(self.pl["G_b"], self.eG, prof)
 
     @staticmethod
     def _grad_l2(x: torch.Tensor, xb: torch.Tensor) -> torch.Tensor:
@@ -436,6 +465,66 @@ class AlternatedStep:
                 for k in ("loss0", "correct0"):
                     if k in slot.bufs:
                         slot.bufs[k].zero_()
+
+
+class WanetStep(AlternatedStep):
+    """The alternated step with the warping trigger (reference train_generator_wanet.py:132-237): the generator is a
+    GridGenerator whose [2][S][S] field is bicubically upsampled, blended with the identity grid at ``grid_rescale``
+    and used to ``grid_sample`` the images (:151-157, :196-202); loss_l2 = MSE(noise_grid, 0) (:212).  Phase
+    structure, streams, poison selection, augmentation, classifiers and optimisers are AlternatedStep's.  No Gaussian
+    blur is drawn (the reference's WaNet loop has none), so the torch RNG stream is consumed by the augmentation only."""
+
+    WARP_GROUPS = 8     # image ranges of the warp backward (partial sums: deterministic, no atomics)
+
+    def _draw(self, targets_cpu, bd_targets_cpu) -> StepRandomness:
+        """train_generator_wanet.py:148, :159, :182, :203-204, :226: num_bd and five augmentation calls -- no blur."""
+        n = targets_cpu.shape[0]
+        n_trg = int((targets_cpu == bd_targets_cpu).sum())
+        num_bd = int(np.sum(np.random.rand(n_trg) < self.opt.pc))
+        return StepRandomness(num_bd, 0.5, 0.5, [self.transforms.sample(n) for _ in range(5)])
+
+    def _gen_slot(self, n):
+        return None
+
+    def _gen_plans(self) -> dict:
+        return {}
+
+    def _setup(self, n: int):
+        super()._setup(n)
+        if getattr(self, "_wpartial_n", 0) != n:
+            self._wpartial = torch.zeros(self.WARP_GROUPS, self.hw, self.hw, 2, dtype=f32, device=self.dev)
+            self._wpartial_n = n
+
+    def _gen_forward(self, x_ptr, n, st, prof) -> None:
+        self.g = self.eG.forward_grid(self.hw, float(self.opt.grid_rescale), st)
+
+    def _trigger_c(self, x_ptr, nb, k1c, st) -> None:
+        ops.check(lib.combat_warp_fwd(x_ptr, self.tab_i[0].data_ptr(), self.g["grid"].data_ptr(), 0, nb, self.hw,
+                                      self.cat_src[self.N:].data_ptr(), st), "warp C")
+
+    def _trigger_g(self, x_ptr, n, k1g, s2) -> None:
+        ops.check(lib.combat_warp_fwd(x_ptr, None, self.g["grid"].data_ptr(), 0, n, self.hw, self.bd.data_ptr(), s2), "warp G")
+
+    def _log_l2_terms(self, n) -> None:
+        ng = self.g["noise_grid"]                      # [H][H][2]; the reference's noise_grid is B equal copies
+        self.acc[0] += ng.pow(2).mean()
+        F = torch.nn.functional
+        e = F.pad(ng[None], (1, 1, 2, 1))              # F.pad of the [B, H, H, 2] tensor pads (H, 2): reproduce that (:214)
+        self.acc[1] += (e[:, :, 1:] - e[:, :, :-1]).pow(2).mean() + (e[:, :, :, 1:] - e[:, :, :, :-1]).pow(2).mean()
+
+    def _gen_backward(self, x_ptr, n, k1g, st, prof) -> None:
+        eG = self.eG
+        ops.check(_zero_grad(eG.fp, st), "zero_grad G")
+        ops.check(lib.combat_warp_bwd(x_ptr, self.d_bd.data_ptr(), self.d_bd2.data_ptr(), self.g["grid"].data_ptr(), 0, n, self.hw,
+                                      self.WARP_GROUPS, self._wpartial.data_ptr(), st), "warp bwd")
+        eG.backward_field(self._wpartial, self.WARP_GROUPS, self.hw, float(self.opt.grid_rescale), float(self.opt.L2_weight), st)
+        if self.world > 1:
+            torch.distributed.all_reduce(eG.fp.grad, group=self.pg)
+
+
+def _zero_grad(fp, st):
+    from .engine import _zero_grad_call
+    return _zero_grad_call(fp, st)
 
 
 class ClassifierStep:

@@ -413,6 +413,36 @@ int combat_dct_u8(const float *x, const float *D, int32_t n, int32_t hw, void *o
 int combat_linear_nhwc(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, const float *W, const float *b,
                        int32_t classes, float *logits, void *stream);
 
+/* ---- WaNet trigger (train_generator_wanet.py:151-157, 196-202, 212; GridGenerator networks/models.py:344-385).
+ * The reference's GridGenerator pools an affine-free InstanceNorm output (spatial mean exactly 0), so its output is
+ * tanh(fc2(lrelu(fc1.bias))) for every input: a constant [2][S][S] field (tests/test_oracle_golden.py pins this
+ * against the reference module).  Images are fp32 [N][3][H][H] planes; grid / noise_grid are fp32 [H][H][2]
+ * ([...][0] = x), shared by the batch (per_image_grid 0) or one per image (1). */
+/* field[2*S*S] = tanh(fc2_weight[nout][nf] . lrelu_0.2(fc1_bias) + fc2_bias)   (models.py:379-384 with f = 0) */
+int combat_grid_head_fwd(const float *fc1_bias, const float *fc2_weight, const float *fc2_bias, int32_t nf, int32_t nout,
+                         float *field, void *stream);
+/* noise_grid = U field U^T (U = the [H][S] matrix of F.upsample(bicubic, align_corners=True), :152);
+ * grid = clamp(identity_grid (1 - rescale) + noise_grid rescale, -1, 1)  (:155-156, identity_grid :560-562) */
+int combat_wanet_grid(const float *field, const float *U, int32_t S, int32_t H, float rescale, float *noise_grid, float *grid,
+                      void *stream);
+/* out[i] = F.grid_sample(x[src_index ? src_index[i] : i], grid, align_corners=True)  bilinear, zeros padding (:157, :202) */
+int combat_warp_fwd(const float *x, const int32_t *src_index, const float *grid, int32_t per_image_grid, int32_t n, int32_t H,
+                    float *out, void *stream);
+/* partial[g][H][H][2] = sum over the images of range g and the channels of (d_out + d_out2) * d grid_sample / d grid */
+int combat_warp_bwd(const float *x, const float *d_out, const float *d_out2, const float *grid, int32_t per_image_grid,
+                    int32_t n, int32_t H, int32_t groups, float *partial, void *stream);
+/* d_x = d grid_sample / d input applied to d_out (d_x is overwritten).  Not on the training path (the images carry no
+ * gradient, :196-202); completes F.grid_sample's backward. */
+int combat_warp_bwd_input(const float *d_out, const float *grid, int32_t per_image_grid, int32_t n, int32_t H, float *d_x,
+                          void *stream);
+/* backward of combat_wanet_grid + combat_grid_head_fwd for a batch-shared grid, plus the gradient of
+ * l2_scale * MSE(noise_grid, 0) (:212, :229): writes d fc1.bias [nf], d fc2.weight [nout][nf], d fc2.bias [nout]
+ * (fc1.weight and the encoder receive exactly 0) and optionally d_field [nout] */
+int combat_wanet_field_bwd(const float *partial, int32_t groups, const float *noise_grid, const float *U, int32_t S, int32_t H,
+                           float rescale, float l2_scale, const float *field, const float *fc1_bias, const float *fc2_weight,
+                           int32_t nf, float *d_fc1_bias, float *d_fc2_weight, float *d_fc2_bias, float *d_field,
+                           void *stream);
+
 #ifdef __cplusplus
 }
 #endif

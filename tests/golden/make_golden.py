@@ -33,7 +33,7 @@ sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
 from classifier_models.preact_resnet import PreActResNet18  # noqa: E402
 from classifier_models.resnet import ResNet18  # noqa: E402
 from defenses.frequency_based.model import FrequencyModel  # noqa: E402
-from networks.models import UnetGenerator  # noqa: E402
+from networks.models import GridGenerator, UnetGenerator  # noqa: E402
 from utils import dct as ref_dct  # noqa: E402
 
 N_SAMPLE = 64  # sampled entries kept per parameter gradient
@@ -475,6 +475,137 @@ def golden_eval_victim():
     save("eval_victim.npz", out)
 
 
+def _wanet_warp(x, noise, rescale=0.15):
+    """train_generator_wanet.py:152-157 with its own calls (F.upsample == F.interpolate)."""
+    h = x.shape[-1]
+    a = torch.linspace(-1, 1, steps=h)
+    gx, gy = torch.meshgrid(a, a, indexing="ij")
+    identity_grid = torch.stack((gy, gx), 2)[None, ...]
+    noise_grid = F.interpolate(noise, size=h, mode="bicubic", align_corners=True).permute((0, 2, 3, 1))
+    grid = torch.clamp(identity_grid * (1 - rescale) + noise_grid * rescale, -1, 1)
+    return F.grid_sample(x, grid, align_corners=True), noise_grid
+
+
+def golden_wanet():
+    """GridGenerator (networks/models.py:344-385), the WaNet warp (train_generator_wanet.py:151-157) with gradients,
+    and two alternated WaNet steps (:132-237) through the reference modules (CIFAR-10 shape, no augmentation)."""
+    out = {}
+
+    class WOpt:
+        s = 2
+
+    torch.manual_seed(2)
+    netg = GridGenerator(WOpt())
+    out["seed"] = np.int64(2)
+    summarize(netg.state_dict().items(), out, "param")
+    x = synth_images(4, 32, 9100).requires_grad_(True)
+    y = netg(x)
+    cot = torch.randn(y.shape, generator=rng(9101))
+    grads = torch.autograd.grad(y, [x] + list(netg.parameters()), cot)
+    out["gg/x"], out["gg/y"], out["gg/cot"] = x.detach().numpy(), y.detach().numpy(), cot.numpy()
+    out["gg/spread"] = np.float64((y - y[:1]).abs().max())               # the output does not depend on the input
+    for (k, _), gr in zip(netg.named_parameters(), grads[1:]):
+        out["gg/gmax/" + k] = np.float64(gr.abs().max())
+        if k.startswith("fc"):
+            out["gg/grad/" + k] = gr.numpy()
+    out["gg/gx_max"] = np.float64(grads[0].abs().max())
+    # warp with per-image fields (more general than the generator's constant one), H = 32 and 64
+    for h in (32, 64):
+        nimg = 3 if h == 32 else 1
+        xs = synth_images(nimg, h, 9200 + h).requires_grad_(True)
+        nz = (torch.rand(nimg, 2, 2, 2, generator=rng(9300 + h)) * 2 - 1).requires_grad_(True)
+        ibd, ng = _wanet_warp(xs, nz)
+        cot = torch.randn(ibd.shape, generator=rng(9400 + h))
+        gx, gn = torch.autograd.grad((ibd * cot).sum() + 0.02 * F.mse_loss(ng, ng * 0), [xs, nz])
+        out["warp%d/x" % h], out["warp%d/noise" % h], out["warp%d/cot" % h] = xs.detach().numpy(), nz.detach().numpy(), cot.numpy()
+        out["warp%d/out" % h], out["warp%d/noise_grid" % h] = ibd.detach().numpy(), ng.detach().numpy()
+        out["warp%d/gx" % h], out["warp%d/gnoise" % h] = gx.numpy(), gn.numpy()
+    # a strongly displaced field: exercises the clamp and the zero padding outside the image
+    xs = synth_images(2, 32, 9500).requires_grad_(True)
+    nz = (torch.rand(2, 2, 2, 2, generator=rng(9501)) * 2 - 1).requires_grad_(True)
+    ibd, ng = _wanet_warp(xs, nz, rescale=0.9)
+    cot = torch.randn(ibd.shape, generator=rng(9502))
+    gx, gn = torch.autograd.grad((ibd * cot).sum(), [xs, nz])
+    out["warpbig/x"], out["warpbig/noise"], out["warpbig/cot"] = xs.detach().numpy(), nz.detach().numpy(), cot.numpy()
+    out["warpbig/out"], out["warpbig/gx"], out["warpbig/gnoise"] = ibd.detach().numpy(), gx.numpy(), gn.numpy()
+    # ---- two alternated steps (train_generator_wanet.py:132-237)
+    b = 16
+    torch.manual_seed(0)
+    netc = PreActResNet18()
+    torch.manual_seed(1)
+    clean = PreActResNet18().eval()
+    torch.manual_seed(2)
+    netg = GridGenerator(WOpt())
+    torch.manual_seed(3)
+    netf = FrequencyModel(num_classes=2, n_input=3, input_size=32).eval()
+    out["seeds"] = np.array([0, 1, 2, 3])
+    opt_c = torch.optim.SGD(netc.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    opt_g = torch.optim.SGD(netg.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    num_bds = [2, 3]
+    out["num_bd"] = np.array(num_bds)
+    keys = ("loss_c", "loss_ce", "loss_l2", "loss_grad_l2", "clean_model_loss", "clean_correct", "bd_correct", "f_correct",
+            "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr", "gnorm_c", "gnorm_g")
+    trace = {k: [] for k in keys}
+    ce = torch.nn.CrossEntropyLoss()
+    for s in range(2):
+        inputs = synth_images(b, 32, 9600 + s)
+        targets = torch.randint(0, 10, (b,), generator=rng(9700 + s))
+        targets[:4] = 0
+        out["step%d/targets" % s] = targets.numpy()        # inputs: synth_images(16, 32, 9600 + s)
+        bd_targets = torch.zeros_like(targets)
+        netg.eval(); clean.eval(); netc.train(); opt_c.zero_grad()
+        trg = (targets == bd_targets).nonzero()[:, 0]
+        ntrg = (targets != bd_targets).nonzero()[:, 0]
+        nb = num_bds[s]
+        chg = inputs[trg[:nb]]
+        ibd, _ = _wanet_warp(chg, netg(chg))
+        tot_in = torch.cat([ibd, inputs[trg[nb:]], inputs[ntrg]], 0)
+        tot_t = torch.cat([bd_targets[trg[:nb]], targets[trg[nb:]], targets[ntrg]], 0)
+        loss_c = ce(netc(tot_in), tot_t)
+        loss_c.backward()
+        trace["gnorm_c"].append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in netc.parameters()))))
+        opt_c.step()
+        with torch.no_grad():
+            clean_preds = clean(inputs)
+        netc.eval(); netg.train(); opt_g.zero_grad()
+        ibd, ng = _wanet_warp(inputs, netg(inputs))
+        with torch.no_grad():
+            pred_clean = netc(inputs)
+        pred_bd = netc(ibd)
+        loss_ce = ce(pred_bd, bd_targets)
+        loss_l2 = F.mse_loss(ng, ng * 0)
+        e, eb = F.pad(ng, (1, 1, 2, 1)), F.pad(ng * 0, (1, 1, 2, 1))
+        loss_grad_l2 = F.mse_loss(e[:, :, 1:] - e[:, :, :-1], eb[:, :, 1:] - eb[:, :, :-1]) + \
+            F.mse_loss(e[:, :, :, 1:] - e[:, :, :, :-1], eb[:, :, :, 1:] - eb[:, :, :, :-1])
+        with torch.no_grad():
+            pred_f = netf(ref_dct.dct_2d(((ibd + 1) / 2 * 255).byte()))
+        cm_preds = clean(ibd)
+        cm_loss = ce(cm_preds, targets)
+        loss = loss_ce + 0.02 * loss_l2 + 0.8 * cm_loss
+        loss.backward()
+        trace["gnorm_g"].append(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in netg.parameters()))))
+        if s == 0:
+            for k, p in netg.named_parameters():
+                if k.startswith("fc"):
+                    out["step0/gradG/" + k] = p.grad.numpy().copy()
+        opt_g.step()
+        for k, v in (("loss_c", loss_c), ("loss_ce", loss_ce), ("loss_l2", loss_l2), ("loss_grad_l2", loss_grad_l2),
+                     ("clean_model_loss", cm_loss)):
+            trace[k].append(float(v))
+        trace["clean_correct"].append(int((pred_clean.argmax(1) == targets).sum()))
+        trace["bd_correct"].append(int((pred_bd.argmax(1) == bd_targets).sum()))
+        trace["f_correct"].append(int((pred_f.argmax(1) == 1).sum()))
+        trace["clean_model_correct"].append(int((clean_preds.argmax(1) == targets).sum()))
+        trace["clean_model_bd_ba"].append(int((cm_preds.argmax(1) == targets).sum()))
+        trace["clean_model_bd_asr"].append(int((cm_preds.argmax(1) == bd_targets).sum()))
+        out["step%d/inputs_bd_sum" % s] = np.float64(ibd.detach().double().sum())
+    out["step_seeds"] = np.array([9600, 9700])
+    for k, v in trace.items():
+        out["trace/" + k] = np.array(v, dtype=np.float64)
+    summarize(netg.state_dict().items(), out, "final/netg")
+    save("wanet.npz", out)
+
+
 def golden_config():
     """Flag names, defaults and types of the reference parser (config.py:4-86)."""
     import json
@@ -513,4 +644,5 @@ if __name__ == "__main__":
     golden_trajectory()
     golden_trajectory_lr2e3()
     golden_eval_victim()
+    golden_wanet()
     golden_config()

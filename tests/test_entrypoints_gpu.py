@@ -81,6 +81,27 @@ def test_celeba_workflow_on_synthetic_data(tmp_path):
     assert "Bd ASR:" in out
 
 
+def test_wanet_workflow_on_synthetic_data(tmp_path):
+    """train_generator_wanet.py (reference :455-603): fresh run, checkpoint with the GridGenerator's 20-entry state
+    dict under the reference's keys, --continue_training, and eval of the warped test images."""
+    cwd = str(tmp_path)
+    run("train_clean_classifier.py", "--saving_prefix", "classifier_clean", "--n_iters", "1", cwd=cwd)
+    out = run("train_generator_wanet.py", "--saving_prefix", "train_generator_wanet", "--load_checkpoint_clean", "classifier_clean",
+              "--n_iters", "1", "--s", "2", "--grid_rescale", "0.15", cwd=cwd)
+    assert "Clean Acc:" in out and "Saving..." in out
+    gen = os.path.join(cwd, "ckpt", "train_generator_wanet_clean", "cifar10", "cifar10_train_generator_wanet_clean.pth.tar")
+    sd = torch.load(gen, map_location="cpu", weights_only=True)
+    assert set(sd) == {"netC", "schedulerC", "optimizerC", "netG", "schedulerG", "optimizerG", "clean_model",
+                       "best_clean_acc", "best_bd_acc", "best_F_acc", "best_clean_model_acc", "best_clean_model_bd_ba",
+                       "best_clean_model_bd_asr", "epoch_current"}
+    assert len(sd["netG"]) == 20 and sd["netG"]["fc2.weight"].shape == (8, 64) and sd["netG"]["fc1.weight"].shape == (64, 512)
+    assert all(torch.isfinite(v).all() for v in sd["netG"].values())
+    assert len(sd["optimizerG"]["state"]) == 20
+    out = run("train_generator_wanet.py", "--saving_prefix", "train_generator_wanet", "--load_checkpoint_clean", "classifier_clean",
+              "--n_iters", "2", "--continue_training", cwd=cwd)
+    assert "Continue training!!" in out
+
+
 def test_data_parallel_step_two_ranks_one_gpu(tmp_path):
     """SURVEY 8(e) without an 8-GPU node: two fresh rank processes share this box's GPU and exchange over gloo
     (tests/dp_rehearsal.py).  After step 1 the all-reduced netC gradient is the sum of the two single-rank

@@ -418,3 +418,87 @@ def test_eval_batch_and_victim_step_match_the_reference_modules(golden):
         assert (num / den) ** 0.5 < (5e-3 if tag == "victim" else 1e-5), (tag, (num / den) ** 0.5)
         check_summary(g, tag + "/after", oc.items(), 1e-4)
     assert r["num_bd"] == 0
+
+
+# ---------------------------------------------------------------- WaNet: GridGenerator, warp, alternated step
+
+
+def test_grid_generator_is_a_constant_field_and_matches_the_reference(golden):
+    """networks/models.py:344-385.  The reference pools an affine-free InstanceNorm output, whose spatial mean is 0
+    by construction: the recorded outputs are the same for every input (spread 3e-8), the encoder's gradients are
+    rounding noise (< 1e-6) next to the head's (O(1)) -- so the trigger is tanh(fc2(lrelu(fc1.bias))), which is what
+    the HIP path computes (combat_amd.engine.GridEngine)."""
+    from combat_amd import nets
+    from oracle import combat_oracle as O
+    g = golden("wanet")
+
+    class WOpt:
+        s = 2
+
+    torch.manual_seed(int(g["seed"]))
+    m = nets.GridGenerator(WOpt())
+    check_summary(g, "param", state(m).items(), 1e-6)
+    p = {k: v.clone().requires_grad_(True) for k, v in state(m).items()}
+    x = T(g["gg/x"]).requires_grad_(True)
+    y = O.grid_generator_forward(p, x)
+    np.testing.assert_allclose(y.detach().numpy(), g["gg/y"], atol=1e-6)
+    assert float(g["gg/spread"]) < 1e-7 and float(g["gg/gx_max"]) < 1e-6
+    names = list(p)
+    grads = torch.autograd.grad(y, [x] + [p[k] for k in names], T(g["gg/cot"]))
+    for k, gr in zip(names, grads[1:]):
+        if k.startswith("fc") and k != "fc1.weight":
+            np.testing.assert_allclose(gr.numpy(), g["gg/grad/" + k], rtol=1e-4, atol=1e-6)
+        else:
+            assert float(g["gg/gmax/" + k]) < 1e-6 and float(gr.abs().max()) < 1e-5, k
+    # the closed form
+    b1, w2, b2 = p["fc1.bias"].detach(), p["fc2.weight"].detach(), p["fc2.bias"].detach()
+    const = torch.tanh(F.linear(F.leaky_relu(b1, 0.2), w2, b2)).reshape(2, 2, 2)
+    assert float((y.detach() - const[None]).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("tag,rescale", [("warp32", 0.15), ("warp64", 0.15), ("warpbig", 0.9)])
+def test_wanet_warp_matches_the_reference_calls(golden, tag, rescale):
+    """train_generator_wanet.py:151-157 (bicubic upsample align_corners=True, identity blend, clamp, bilinear
+    grid_sample) with gradients w.r.t. the images and the warp field."""
+    from oracle import combat_oracle as O
+    g = golden("wanet")
+    x, nz = T(g[tag + "/x"]).requires_grad_(True), T(g[tag + "/noise"]).requires_grad_(True)
+    ibd, ng = O.wanet_warp(x, nz, rescale)
+    np.testing.assert_allclose(ibd.detach().numpy(), g[tag + "/out"], atol=2e-6)
+    loss = (ibd * T(g[tag + "/cot"])).sum() + (0.02 * F.mse_loss(ng, ng * 0) if tag != "warpbig" else 0.0)
+    gx, gn = torch.autograd.grad(loss, [x, nz])
+    np.testing.assert_allclose(gx.numpy(), g[tag + "/gx"], atol=2e-6)
+    np.testing.assert_allclose(gn.numpy(), g[tag + "/gnoise"], rtol=1e-4, atol=1e-4)
+    assert tuple(O.wanet_identity_grid(8).shape) == (1, 8, 8, 2)
+    assert float(O.wanet_identity_grid(8)[0, 2, 5, 0]) == pytest.approx(-1 + 2 * 5 / 7)     # [..., 0] is x (the column)
+
+
+def test_wanet_alternated_step_trace(golden):
+    """Two WaNet steps (train_generator_wanet.py:132-237) against the reference modules + torch.optim.SGD."""
+    from combat_amd import nets
+    from oracle import combat_oracle as O
+    g = golden("wanet")
+
+    class WOpt:
+        s = 2
+
+    seeds = [int(v) for v in g["seeds"]]
+    mods = [seeded(nets.PreActResNet18, seeds[0]), seeded(nets.PreActResNet18, seeds[1]),
+            seeded(lambda: nets.GridGenerator(WOpt()), seeds[2]), seeded(lambda: nets.FrequencyModel(2, 3, 32), seeds[3])]
+    oc, ok, og, of = (state(m) for m in mods)
+    bufs_c, bufs_g = [None] * len(O.trainable_names(oc)), [None] * len(O.trainable_names(og))
+    cfg = O.StepConfig(trigger="wanet")
+    s_img, s_lab = (int(v) for v in g["step_seeds"])
+    for s in range(2):
+        x = synth_images(16, 32, s_img + s)
+        t = torch.randint(0, 10, (16,), generator=torch.Generator().manual_seed(s_lab + s))
+        t[:4] = 0
+        assert torch.equal(t, T(g["step%d/targets" % s]))
+        r = O.alternated_step(oc, og, ok, of, bufs_c, bufs_g, x, t, O.StepRandomness(int(g["num_bd"][s]), 0.0, 0.0), cfg,
+                              as_written=(s == 1))
+        for k in ("loss_c", "loss_ce", "loss_l2", "loss_grad_l2", "clean_model_loss", "gnorm_c", "gnorm_g"):
+            ref = float(g["trace/" + k][s])
+            assert abs(r[k] - ref) < 2e-4 * max(1.0, abs(ref)) + 1e-7, (s, k, r[k], ref)
+        for k in ("clean_correct", "bd_correct", "f_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr"):
+            assert r[k] == int(g["trace/" + k][s]), (s, k)
+    check_summary(g, "final/netg", og.items(), 1e-4)

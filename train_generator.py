@@ -21,7 +21,7 @@ from combat_amd import api, dist as cdist
 from combat_amd.data import get_dataloader
 from combat_amd.log import SummaryWriter, progress_bar
 from combat_amd.nets import FrequencyModel, UnetGenerator, configure_dataset, default_classifier
-from combat_amd.step import AlternatedStep, create_targets_bd  # noqa: F401  (re-exported like the reference)
+from combat_amd.step import AlternatedStep, WanetStep, create_targets_bd  # noqa: F401  (re-exported like the reference)
 
 
 def create_dir(path_dir):
@@ -46,7 +46,8 @@ def _step_of(netC, netG, clean_model, netF, opt) -> AlternatedStep:
     st = netC.__dict__.get("_alt_step")
     if st is None:
         pg = torch.distributed.group.WORLD if torch.distributed.is_initialized() else None
-        st = AlternatedStep(netC, netG, clean_model, netF, opt, process_group=pg)
+        cls = WanetStep if getattr(netG, "arch", "") == "gridgen" else AlternatedStep
+        st = cls(netC, netG, clean_model, netF, opt, process_group=pg)
         netC.__dict__["_alt_step"] = st
     return st
 
@@ -169,7 +170,11 @@ def detector_checkpoint_path(opt):
     return os.path.join(folder, opt.F_model, name)
 
 
-def main():
+def main(get_model=None, train=None, eval=None):
+    """``get_model`` / ``train`` / ``eval`` default to this module's; train_generator_wanet.py passes its own."""
+    get_model = get_model or globals()["get_model"]
+    train = train or globals()["train"]
+    eval = eval or globals()["eval"]
     opt = config.get_arguments().parse_args()
     configure_dataset(opt)
     rank, local_rank, world = cdist.init()
