@@ -173,7 +173,14 @@ extern "C" int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32
     if (dW && (!db || !pooled)) return COMBAT_EINVAL;
     hipStream_t st = as_stream(stream);
     const int in_ = C * (hw / 4) * (hw / 4);
-    if (in_ * 4 > 60 * 1024) return COMBAT_EINVAL;
+    if (in_ * 4 > 150 * 1024) return COMBAT_EINVAL;
+    static bool attr = false;
+    if (!attr) {     // 224 x 224 inputs pool to 7 x 7 x 512 features: 98 KB of LDS
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_bwd_feat_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr = true;
+    }
     hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(n), dim3(256), in_ * 4, st, logits, targets, loss_weight, n, hw, C,
                        classes, W, dlogits, reinterpret_cast<__bf16 *>(d_feat));
     CB_LAUNCH_CHECK();

@@ -253,11 +253,42 @@ __global__ __launch_bounds__(256) void augment_fwd_kernel(const float *__restric
     }
 }
 
+// Images too large for one workgroup's LDS (hw > 96: ImageNet-10's 224 x 224): the same geometry, one thread per
+// output pixel, gathering from global memory.
+__global__ __launch_bounds__(256) void augment_fwd_big_kernel(const float *__restrict__ x, const int *__restrict__ index,
+                                                              const float *__restrict__ params, int hw,
+                                                              uint4 *__restrict__ out_c8, float *__restrict__ out_f32) {
+    const int hw2 = hw * hw, img = blockIdx.y, o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= hw2) return;
+    const float *src = x + (long)(index ? index[img] : img) * 3 * hw2;
+    const AugGeom g = aug_geom(params, img, hw);
+    const int yo = o / hw, xo0 = o - yo * hw;
+    const int xo = g.flip ? hw - 1 - xo0 : xo0;
+    float v[3];
+    if (g.rot) {
+        const float dx = xo - g.cx, dy = yo - g.cy;
+        const float sx = g.ca * dx - g.sa * dy + g.cx, sy = g.sa * dx + g.ca * dy + g.cy;
+        const float fx = floorf(sx), fy = floorf(sy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float ax = sx - fx, ay = sy - fy;
+        for (int c = 0; c < 3; ++c) {
+            const float *pl = src + c * hw2;
+            v[c] = (1.f - ay) * ((1.f - ax) * crop_at(pl, hw, g, x0, y0) + ax * crop_at(pl, hw, g, x0 + 1, y0)) +
+                   ay * ((1.f - ax) * crop_at(pl, hw, g, x0, y0 + 1) + ax * crop_at(pl, hw, g, x0 + 1, y0 + 1));
+        }
+    } else {
+        for (int c = 0; c < 3; ++c) v[c] = crop_at(src + c * hw2, hw, g, xo, yo);
+    }
+    out_c8[(long)img * hw2 + o] = hilo_px(v[0], v[1], v[2]);
+    if (out_f32)
+        for (int c = 0; c < 3; ++c) out_f32[((long)img * 3 + c) * hw2 + o] = v[c];
+}
+
 __device__ __forceinline__ void crop_scatter(float *plane, int hw, const AugGeom &g, int u, int v, float val) {
     if ((unsigned)u >= (unsigned)hw || (unsigned)v >= (unsigned)hw) return;
     const int sx = u + g.ox, sy = v + g.oy;
     if ((unsigned)sx >= (unsigned)hw || (unsigned)sy >= (unsigned)hw) return;
-    atomicAdd(plane + sy * hw + sx, val);  // LDS atomic
+    atomicAdd(plane + sy * hw + sx, val);  // LDS atomic (global in the big-image variant)
 }
 
 __global__ __launch_bounds__(256) void augment_bwd_kernel(const __bf16 *__restrict__ d_c8, int cch,
@@ -294,6 +325,36 @@ __global__ __launch_bounds__(256) void augment_bwd_kernel(const __bf16 *__restri
     for (int o = tid; o < 3 * hw2; o += 256) d_x[(long)img * 3 * hw2 + o] = sm[o];
 }
 
+// hw > 96: scatter with global fp32 atomics into d_x (zeroed by the launcher unless `accumulate`)
+__global__ __launch_bounds__(256) void augment_bwd_big_kernel(const __bf16 *__restrict__ d_c8, int cch,
+                                                              const float *__restrict__ params, int hw,
+                                                              float *__restrict__ d_x) {
+    const int hw2 = hw * hw, img = blockIdx.y, o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= hw2) return;
+    const AugGeom g = aug_geom(params, img, hw);
+    const int yo = o / hw, xo0 = o - yo * hw;
+    const int xo = g.flip ? hw - 1 - xo0 : xo0;
+    const __bf16 *gp = d_c8 + ((long)img * hw2 + o) * cch;
+    const float gv[3] = {(float)gp[0], (float)gp[1], (float)gp[2]};
+    float *dst = d_x + (long)img * 3 * hw2;
+    if (g.rot) {
+        const float dx = xo - g.cx, dy = yo - g.cy;
+        const float sx = g.ca * dx - g.sa * dy + g.cx, sy = g.sa * dx + g.ca * dy + g.cy;
+        const float fx = floorf(sx), fy = floorf(sy);
+        const int x0 = (int)fx, y0 = (int)fy;
+        const float ax = sx - fx, ay = sy - fy;
+        for (int c = 0; c < 3; ++c) {
+            float *pl = dst + c * hw2;
+            crop_scatter(pl, hw, g, x0, y0, (1.f - ay) * (1.f - ax) * gv[c]);
+            crop_scatter(pl, hw, g, x0 + 1, y0, (1.f - ay) * ax * gv[c]);
+            crop_scatter(pl, hw, g, x0, y0 + 1, ay * (1.f - ax) * gv[c]);
+            crop_scatter(pl, hw, g, x0 + 1, y0 + 1, ay * ax * gv[c]);
+        }
+    } else {
+        for (int c = 0; c < 3; ++c) crop_scatter(dst + c * hw2, hw, g, xo, yo, gv[c]);
+    }
+}
+
 // ------------------------------------------------------------------ DCT of the uint8-truncated image
 // one workgroup per (channel, image); LDS (floats): Dl [hw][hw+1] = D, Dr [hw][hw] = D^T, A, B [hw][hw+1]
 __global__ __launch_bounds__(256) void dct_u8_kernel(const float *__restrict__ x, const float *__restrict__ D, int hw,
@@ -315,6 +376,44 @@ __global__ __launch_bounds__(256) void dct_u8_kernel(const float *__restrict__ x
     mm4(B, lp, Dr, A, hw, hw, tid);     // A = D q D^T
     __syncthreads();
     for (int o = tid; o < hw2; o += 256) store_hilo(out_c8 + ((long)img * hw2 + o) * 8, c, A[o]);
+}
+
+// hw > 64 (224): one workgroup per (16-row strip, channel, image).  T = D[strip] q in LDS, then Y[strip] = T D^T.
+// LDS: Ds [16][hw] (the strip of D), Ts [16][hw].  Metric only (the detector's accuracy), ~4 GFLOP fp32 per 32 images.
+__global__ __launch_bounds__(256) void dct_u8_big_kernel(const float *__restrict__ x, const float *__restrict__ D, int hw,
+                                                         __bf16 *__restrict__ out_c8) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int hw2 = hw * hw, tid = threadIdx.x, r0 = blockIdx.x * 16, c = blockIdx.y, img = blockIdx.z;
+    float *Ds = sm, *Ts = sm + 16 * hw;
+    for (int o = tid; o < 16 * hw; o += 256) Ds[o] = D[r0 * hw + o];
+    __syncthreads();
+    const float *plane = x + ((long)img * 3 + c) * hw2;
+    for (int j = tid; j < hw; j += 256) {     // column j of the strip: T[r][j] = sum_k D[r0 + r][k] q[k][j]
+        float acc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int k = 0; k < hw; ++k) {
+            const float q = (float)(unsigned char)(int)((plane[k * hw + j] + 1.f) / 2.f * 255.f);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(Ds[r * hw + k], q, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Ts[r * hw + j] = acc[r];
+    }
+    __syncthreads();
+    for (int j = tid; j < hw; j += 256) {     // Y[r][j] = sum_k T[r][k] D[j][k]
+        float acc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const float *dj = D + (long)j * hw;
+        for (int k = 0; k < hw; ++k) {
+            const float d = dj[k];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(Ts[r * hw + k], d, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) store_hilo(out_c8 + ((long)img * hw2 + (r0 + r) * hw + j) * 8, c, acc[r]);
+    }
 }
 
 template <typename K>
@@ -358,8 +457,14 @@ extern "C" int combat_trigger_bwd(const float *x, const void *noise, const float
 
 extern "C" int combat_augment_fwd(const float *x, const int32_t *src_index, const float *params, int32_t n,
                                   int32_t hw, void *out_c8, float *out_f32, void *stream) {
-    if (!x || !out_c8 || n < 0 || hw < 2 || hw > 96) return COMBAT_EINVAL;
+    if (!x || !out_c8 || n < 0 || hw < 2 || hw > 1024) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
+    if (hw > 96) {
+        hipLaunchKernelGGL(augment_fwd_big_kernel, dim3((hw * hw + 255) / 256, n), dim3(256), 0, as_stream(stream), x, src_index,
+                           params, hw, reinterpret_cast<uint4 *>(out_c8), out_f32);
+        CB_LAUNCH_CHECK();
+        return COMBAT_OK;
+    }
     const int bytes = 3 * hw * hw * 4;
     if (set_smem(augment_fwd_kernel, bytes)) return COMBAT_ELAUNCH;
     hipLaunchKernelGGL(augment_fwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), x, src_index, params, hw,
@@ -370,8 +475,16 @@ extern "C" int combat_augment_fwd(const float *x, const int32_t *src_index, cons
 
 extern "C" int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const float *params, int32_t n, int32_t hw,
                                   float *d_x, int32_t accumulate, void *stream) {
-    if (!d_c8 || !d_x || c8_channels < 3 || n < 0 || hw < 2 || hw > 96) return COMBAT_EINVAL;
+    if (!d_c8 || !d_x || c8_channels < 3 || n < 0 || hw < 2 || hw > 1024) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
+    if (hw > 96) {
+        hipStream_t st = as_stream(stream);
+        if (!accumulate && hipMemsetAsync(d_x, 0, (size_t)n * 3 * hw * hw * sizeof(float), st) != hipSuccess) return COMBAT_ELAUNCH;
+        hipLaunchKernelGGL(augment_bwd_big_kernel, dim3((hw * hw + 255) / 256, n), dim3(256), 0, st,
+                           reinterpret_cast<const __bf16 *>(d_c8), c8_channels, params, hw, d_x);
+        CB_LAUNCH_CHECK();
+        return COMBAT_OK;
+    }
     const int bytes = 3 * hw * hw * 4;
     if (set_smem(augment_bwd_kernel, bytes)) return COMBAT_ELAUNCH;
     hipLaunchKernelGGL(augment_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream),
@@ -381,8 +494,14 @@ extern "C" int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const f
 }
 
 extern "C" int combat_dct_u8(const float *x, const float *D, int32_t n, int32_t hw, void *out_c8, void *stream) {
-    if (!x || !D || !out_c8 || n < 0 || hw < 4 || hw > 64 || (hw & 3)) return COMBAT_EINVAL;
+    if (!x || !D || !out_c8 || n < 0 || hw < 4 || hw > 256 || (hw & 3) || (hw > 64 && (hw & 15))) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
+    if (hw > 64) {
+        hipLaunchKernelGGL(dct_u8_big_kernel, dim3(hw / 16, 3, n), dim3(256), 2 * 16 * hw * 4, as_stream(stream), x, D, hw,
+                           reinterpret_cast<__bf16 *>(out_c8));
+        CB_LAUNCH_CHECK();
+        return COMBAT_OK;
+    }
     const int bytes = (4 * hw * hw + 2 * hw) * 4;
     if (set_smem(dct_u8_kernel, bytes)) return COMBAT_ELAUNCH;
     hipLaunchKernelGGL(dct_u8_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x, D, hw,

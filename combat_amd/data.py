@@ -59,6 +59,22 @@ def _load_celeba(root: str, train: bool, hw: int) -> Tuple[np.ndarray, np.ndarra
     return np.ascontiguousarray(img), labels.astype(np.int64)
 
 
+def _load_imagenet10(root: str, train: bool, hw: int) -> Tuple[np.ndarray, np.ndarray]:
+    """ImageNet-10 as the reference uses it (utils/dataloader.py:83-95: torchvision.datasets.ImageNet under
+    <data_root>/imagenet10, split train / val, resized to 224 x 224 by get_transform :27), from a pre-decoded cache
+    `imagenet10_{train,val}_224.npz` with uint8 `images` [N,224,224,3] (or [N,3,224,224]) and int `labels` [N] (0..9).
+    JPEG decoding is outside this package, as for CelebA; the file is memory-mapped when stored uncompressed."""
+    path = os.path.join(root, "imagenet10_%s_%d.npz" % ("train" if train else "val", hw))
+    if not os.path.exists(path):
+        raise FileNotFoundError("ImageNet-10 cache %r not found (uint8 images [N,%d,%d,3] + labels [N]); nothing is "
+                                "downloaded.  --synthetic runs the same shapes on generated data." % (path, hw, hw))
+    z = np.load(path, mmap_mode="r")
+    img = z["images"]
+    if img.shape[-1] == 3:
+        img = img.transpose(0, 3, 1, 2)
+    return np.ascontiguousarray(img), np.asarray(z["labels"]).astype(np.int64)
+
+
 def synthetic_cifar10(n: int, seed: int, hw: int = 32, classes: int = 10) -> Tuple[np.ndarray, np.ndarray]:
     g = np.random.default_rng(seed)
     return g.integers(0, 256, (n, 3, hw, hw), dtype=np.uint8), g.integers(0, classes, n).astype(np.int64)
@@ -147,13 +163,15 @@ def get_dataloader(opt, train: bool = True, pretensor_transform: bool = False, b
     """Same call shape as the reference's ``get_dataloader`` (utils/dataloader.py:98,
     utils/dataloader_cleanbd.py:161 with ``poisoned=True``)."""
     bs = opt.bs if bs is None else bs
-    if opt.dataset not in ("cifar10", "celeba"):
-        raise Exception("dataset %r is a later SURVEY section-8(f) row (cifar10 and celeba are wired)" % opt.dataset)
+    if opt.dataset not in ("cifar10", "celeba", "imagenet10"):
+        raise Exception("Invalid Dataset")
     if getattr(opt, "synthetic", False):
         n = getattr(opt, "synthetic_size", 0) or (CIFAR_TRAIN if train else CIFAR_TEST)
         x, y = synthetic_cifar10(n, 1234 if train else 4321, opt.input_height, opt.num_classes)
     elif opt.dataset == "celeba":
         x, y = _load_celeba(opt.data_root, train, opt.input_height)
+    elif opt.dataset == "imagenet10":
+        x, y = _load_imagenet10(opt.data_root, train, opt.input_height)
     else:
         x, y = _load_cifar10(opt.data_root, train)
     if getattr(opt, "debug", False):                         # utils/dataloader.py:118-119

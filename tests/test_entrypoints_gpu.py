@@ -102,6 +102,21 @@ def test_wanet_workflow_on_synthetic_data(tmp_path):
     assert "Continue training!!" in out
 
 
+def test_wanet_imagenet10_workflow_on_synthetic_data(tmp_path):
+    """BASELINE config 5: --dataset imagenet10 (224 x 224, 10 classes, ResNet18(input_size=224), bs forced to 32 as
+    reference train_generator_wanet.py:471-476).  The reference itself raises KeyError here."""
+    cwd = str(tmp_path)
+    common = ["--dataset", "imagenet10", "--synthetic_size", "64", "--n_iters", "1"]
+    out = run("train_clean_classifier.py", "--saving_prefix", "classifier_clean", *common, cwd=cwd)
+    out = run("train_generator_wanet.py", "--saving_prefix", "train_generator_wanet", "--load_checkpoint_clean", "classifier_clean",
+              *common, cwd=cwd)
+    assert "Clean Acc:" in out and "Saving..." in out
+    gen = os.path.join(cwd, "ckpt", "train_generator_wanet_clean", "imagenet10", "imagenet10_train_generator_wanet_clean.pth.tar")
+    sd = torch.load(gen, map_location="cpu", weights_only=True)
+    assert sd["netC"]["linear.weight"].shape == (10, 512 * 49) and len(sd["netG"]) == 20
+    assert all(torch.isfinite(v.float()).all() for v in sd["netC"].values())
+
+
 def test_data_parallel_step_two_ranks_one_gpu(tmp_path):
     """SURVEY 8(e) without an 8-GPU node: two fresh rank processes share this box's GPU and exchange over gloo
     (tests/dp_rehearsal.py).  After step 1 the all-reduced netC gradient is the sum of the two single-rank

@@ -261,26 +261,45 @@ def test_wanet_step_sampled_randomness_ragged_and_api(golden):
 
 
 def test_wanet_step_imagenet10_shape():
-    """BASELINE config 5's shape (imagenet10: 3 x 224 x 224, 10 classes, ResNet18(input_size=224), batch 32 -> here 4):
-    one WaNet step runs and stays finite, and the warp equals the oracle's at 224 x 224.  No reference parity for the
-    classifier at this size (the ResNet18 224 head is outside the recorded goldens: "parity unpinned")."""
+    """BASELINE config 5's shape (imagenet10: 3 x 224 x 224, 10 classes, ResNet18(input_size=224), batch 32 -> here 4).
+    The reference cannot run this configuration (its input_size2scaler has no 224 entry: SURVEY D4), so there is no
+    reference result to be in parity with -- "parity unpinned" against the reference; the check is against the CPU
+    oracle, which is size-generic (avg_pool2d(4) of the 28 x 28 map -> 7 x 7 x 512 features), driven with the
+    bf16-emulating ResNet18: Phase C from the identical start state (loss 1e-2, gradient norm 3e-2), the fp32 warp terms
+    (1e-4), Phase G's classifier losses as bounds (netC differs by then between two bf16 realisations, as in the CelebA
+    test), and the warp itself at 224 x 224 (fp32 coordinate rounding grows with H: 2e-5 * H / 32)."""
     from combat_amd import api, nets, step as step_mod
     from oracle import combat_oracle as O
     mk = lambda: nets.ResNet18(num_classes=10, input_size=224)
     netc, clean = seeded(mk, 1), seeded(mk, 2)
     netg = seeded(lambda: nets.GridGenerator(_grid_opt()), 3)
     netf = seeded(lambda: nets.FrequencyModel(2, 3, 224), 4).eval()
+    oc, ok, og, of = (_oracle_state(m) for m in (netc, clean, netg, netf))
+    x = synth_images(4, 224, 5)
+    t = torch.tensor([0, 3, 0, 7])
+    cfg = O.StepConfig(num_classes=10, classifier="resnet18", trigger="wanet")
+    ref = O.alternated_step(oc, og, ok, of, [None] * len(O.trainable_names(oc)), [None] * len(O.trainable_names(og)), x, t,
+                            O.StepRandomness(1, 0.5, 0.5, [None] * 5), cfg, clf_fn=E.resnet_forward_emu)
     opt = WOpt()
     opt.input_height = opt.input_width = 224
     opt.dataset = "imagenet10"
     st = step_mod.WanetStep(netc.cuda(), netg.cuda(), clean.cuda().eval(), netf.cuda().eval(), opt)
-    x = synth_images(4, 224, 5)
-    t = torch.tensor([0, 3, 0, 7])
+    st.keep_grads = True
     st.run(x.cuda(), t, step_mod.StepRandomness(1, 0.5, 0.5, [None] * 5))
     torch.cuda.synchronize()
     m = st.read_metrics()
     assert all(np.isfinite(v) for v in m.values()), m
+    assert abs(m["loss_c_sum"] - ref["loss_c"]) < 1e-2 * max(1.0, abs(ref["loss_c"])), (m["loss_c_sum"], ref["loss_c"])
+    gn_c = float(st.eC.fp.grad.double().norm())
+    assert abs(gn_c - ref["gnorm_c"]) < 3e-2 * ref["gnorm_c"], (gn_c, ref["gnorm_c"])
+    assert abs(m["loss_l2_sum"] - ref["loss_l2"]) < 1e-4 * ref["loss_l2"]
+    assert abs(m["loss_grad_l2_sum"] - ref["loss_grad_l2"]) < 1e-4 * ref["loss_grad_l2"]
+    assert abs(m["clean_model_loss_sum"] - ref["clean_model_loss"]) < 0.05 * max(1.0, abs(ref["clean_model_loss"]))
+    assert abs(m["loss_ce_sum"] - ref["loss_ce"]) < 0.15 * max(1.0, abs(ref["loss_ce"]))
+    gn_g = float(st.eG.fp.grad.double().norm())
+    assert 0.5 * ref["gnorm_g"] < gn_g < 2.0 * ref["gnorm_g"], (gn_g, ref["gnorm_g"])
+    assert abs(m["f_correct"] - ref["f_correct"]) <= 1
     ours = api.create_backdoor(netg, x.cuda(), opt)
     fld = O.grid_generator_forward({k: v.cpu() for k, v in netg.state_dict().items()}, x[:1]).expand(4, -1, -1, -1)
-    ref, _ = O.wanet_warp(x, fld, opt.grid_rescale)
-    assert float((ours.cpu() - ref).abs().max()) < 2e-5
+    refw, _ = O.wanet_warp(x, fld, opt.grid_rescale)
+    assert float((ours.cpu() - refw).abs().max()) < 2e-5 * 224 / 32
