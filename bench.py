@@ -42,7 +42,10 @@ sys.path.insert(0, ROOT)
 
 METRIC = "images/sec per alternated generator+surrogate step, CIFAR-10 bs=128, 1/2/4/8 GPU"
 PEAK_BF16_TFLOPS = 2500.0
-PMC_TRAFFIC_CSV = ("r02_pmc_hbm_traffic.csv", "r01_k_pmc_hbm_traffic.csv")   # newest first
+def _pmc_traffic_files():
+    """profiles/rNN_<tag>_pmc_hbm_traffic.csv, newest (highest round, then tag) first."""
+    import glob
+    return [os.path.basename(p) for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")), reverse=True)]
 TILE_NAMES = {1: "conv_gemm_kernel<128,128>", 2: "conv_gemm_kernel<128,64>", 3: "conv_gemm_kernel<64,64>",
               4: "conv_gemm_kernel<128,16>", 5: "conv_gemm_kernel<64,128>",
               6: "conv3x3_halo1_kernel<256,64>", 7: "conv3x3_halo1_kernel<128,128>", 8: "conv3x3_halo1_kernel<128,64>",
@@ -150,7 +153,7 @@ def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2
     per the gfx950 correction + WRITE_SIZE, separate --pmc runs): PMC counters cannot be collected from
     inside this process.  (bytes, file) or (None, None) if no summary is present."""
-    for name in PMC_TRAFFIC_CSV:
+    for name in _pmc_traffic_files():
         path = os.path.join(ROOT, "profiles", name)
         try:
             tot = cnt = 0.0
