@@ -39,6 +39,16 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// Ablation switches for profiling builds (results are garbage; tools/conv_bench.py timings only):
+//   COMBAT_ABL_NOMFMA  the MFMA blocks become one VALU op per fragment pair (fragment reads stay alive)
+//   COMBAT_ABL_NODMA   no weight / halo DMA after the first halo patch (the counted waits shrink accordingly)
+//   COMBAT_ABL_NOREAD  no LDS fragment reads (the MFMAs run on whatever the registers hold)
+#if defined(COMBAT_ABL_NODMA)
+#define ABL_DMA(x) 0
+#else
+#define ABL_DMA(x) (x)
+#endif
+
 constexpr unsigned kOob = kDmaOob;
 
 struct DmaParams {
@@ -155,7 +165,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         const int tap = a.mode == 0 ? t : 8 - t;
         const int soff = (tap * C + cc * 64) * 2;
 #pragma unroll
-        for (int j = 0; j < WPW; ++j)
+        for (int j = 0; j < ABL_DMA(WPW); ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void_t *)(wring + slot * WBYTES + (wid + NW * j) * 1024), 16,
                                                      wvoff[j], soff, 0, 0);
     };
@@ -201,7 +211,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     }
     auto issue_h = [&](int cc, int hbuf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < HPW; ++j)
+        for (int j = 0; j < (cc == 0 ? HPW : ABL_DMA(HPW)); ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(halo + hbuf * HBYTES + (wid + NW * j) * 1024), 16,
                                                      hvoff[j], cc * 128, 0, 0);
     };
@@ -244,10 +254,17 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         const unsigned char *wb = wring + (t % 3) * WBYTES;
         // TW 4: an odd filter row flips the row parity of the rotation key = the other k-step's slot (s0 ^ 4)
         constexpr int kk = (TW == 4 && (dy & 1)) ? (ks ^ 1) : ks;
+#ifndef COMBAT_ABL_NOREAD
 #pragma unroll
         for (int j = 0; j < T::FM; ++j) fp[j] = *reinterpret_cast<const bf16x8_t *>(hb + pa[kk][j][dx]);
 #pragma unroll
         for (int i = 0; i < T::FN; ++i) fw[i] = *reinterpret_cast<const bf16x8_t *>(wb + wa[ks] + i * 2048);
+#else
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j) asm volatile("" : "+v"(fp[j]));
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i) asm volatile("" : "+v"(fw[i]));
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     auto mfma_frags = [&](const bf16x8_t (&fp)[T::FM], const bf16x8_t (&fw)[T::FN]) __attribute__((always_inline)) {
@@ -255,7 +272,11 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         for (int i = 0; i < T::FN; ++i)
 #pragma unroll
             for (int j = 0; j < T::FM; ++j)
+#ifndef COMBAT_ABL_NOMFMA
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fp[j], acc[i][j], 0, 0, 0);
+#else
+                acc[i][j][0] += (float)fw[i][0] * (float)fp[j][0];
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -294,6 +315,12 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     constexpr int PF_T = 4;
     const int nchunks = p.nchunks;
     bf16x8_t fpA[T::FM], fwA[T::FN], fpB[T::FM], fwB[T::FN];
+#ifdef COMBAT_ABL_NOREAD
+#pragma unroll
+    for (int j = 0; j < T::FM; ++j) fpA[j] = fpB[j] = bf16x8_t{};
+#pragma unroll
+    for (int i = 0; i < T::FN; ++i) fwA[i] = fwB[i] = bf16x8_t{};
+#endif
     static_assert(T::FM == RPW / 16 && T::FN == BN / 16, "wave tile");
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -323,8 +350,8 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         read_frags(fpB, fwB, TT{}, I1{}, HBUF{});                                                            \
         mfma_frags(fpA, fwA);                                                                                \
         if (!(last && t == 8)) {                                                                             \
-            constexpr int n_w = (last && t >= 7) ? 0 : WPW;                                                  \
-            constexpr int n_h = (!last && (t == 1 || t == 2)) ? HPW : 0;                                     \
+            constexpr int n_w = (last && t >= 7) ? 0 : ABL_DMA(WPW);                                         \
+            constexpr int n_h = (!last && (t == 1 || t == 2)) ? ABL_DMA(HPW) : 0;                            \
             constexpr int n_e = (last && (t == PF_T + 1 || t == PF_T + 2)) ? NPF : 0;                        \
             wait_vm_lgkm0<n_w + n_h + n_e>();                                                                \
             block_barrier();                                                                                 \

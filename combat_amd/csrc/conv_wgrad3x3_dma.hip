@@ -20,9 +20,6 @@
 // accumulator registers).
 #include "conv_common.hpp"
 
-#ifndef COMBAT_EXPW
-#define COMBAT_EXPW 0
-#endif
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -45,12 +42,10 @@ extern "C" int combat_debug_set_stamps_wgrad(void *p) { g_stamps_wgrad_host = (u
 #define WCLK() 0ull
 #endif
 
-__device__ __forceinline__ s16x4_t tr16d(const unsigned char *p) {
-#if COMBAT_EXPW == 1
-    return *reinterpret_cast<const s16x4_t *>(p);
-#endif
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4_t *)(reinterpret_cast<uintptr_t>(p)));
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+// p: an LDS pointer held in a VGPR plus a compile-time byte offset -> "ds_read_b64_tr_b16 v, v offset:imm"
+__device__ __forceinline__ s16x4_t tr16d(const lds_u8 *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t *)(const_cast<lds_u8 *>(p)));
 }
 
 __device__ __forceinline__ bf16x8_t join8(const s16x4_t lo, const s16x4_t hi) {
@@ -74,6 +69,14 @@ __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
 
 // HPW = x halo pieces (8 rows each) per wave (compile time: the counted vmcnt waits need the DMA count
 // of a stage), NS = stages in the LDS ring (NS - 1 patches are in flight ahead of the one being consumed)
+// Where a patch's 2 600 cycles go (per-wave in-kernel stamps, 16 patches per workgroup): all eight waves issue their
+// DMA pieces (400), then compute -- the older wave of each SIMD finishes its 36 MFMAs in ~1 500 cycles, the younger one
+// ~400 later (oldest-first arbitration) -- then everyone meets at the barrier: 1 152 cycles of MFMA per SIMD in
+// 2 600.  Without the DMA (ablation build) a patch takes 1 660.  Tried: the two waves of a SIMD half a patch apart (waves
+// 0-3 issue patch i + 2 then compute patch i while waves 4-7 compute patch i - 1 then issue; four-stage ring): the
+// loop 44.8 k -> 38.2 k cycles, the launch and the step unchanged -- the 96-KB ring and 226 registers keep the
+// input-gradient chain's workgroups off the CU (72 KB and 162 registers leave them room), and inside the step that
+// sharing, not this loop, sets the pace.
 template <int HPW, int NS>
 __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -92,7 +95,9 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     if (t_begin >= t_end) return;
 
     const int C = a.C, K = a.K, H = a.H, W = a.W;
-    constexpr int stage_bytes = 64 * 128 + HPW * 8192;      // [dy tile | x halo patch]
+    // LDS: [x halo patches of the NS slots | dy tiles of the NS slots].  Grouped by operand so that the slot offset of a
+    // fragment read folds into its 16-bit immediate: four 16-KB x slots span exactly 64 KB -> ONE set of address registers.
+    constexpr int XBYTES = HPW * 8192, DYBYTES = 64 * 128, DYBASE = NS * XBYTES;
     constexpr int NDMA = 1 + HPW;                           // DMA instructions per wave and stage
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t dyrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.dy), 0, p.dy_bytes, 0x00020000);
@@ -148,16 +153,16 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     };
     auto issue_piece = [&](auto j_tag, auto slot_tag) __attribute__((always_inline)) {
         constexpr int j = decltype(j_tag)::value;
-        constexpr int sbase = decltype(slot_tag)::value * stage_bytes;
+        constexpr int slot_i = decltype(slot_tag)::value;
         if constexpr (j == 0) {
             const unsigned off = is_img0 + dti[0] < a.N ? (unsigned)(is_dorg + drel[0]) : kOob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyrsrc, (lds_void_t *)(smem + sbase + wid * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyrsrc, (lds_void_t *)(smem + DYBASE + slot_i * DYBYTES + wid * 1024), 16, off, 0, 0, 0);
         } else if constexpr (j <= HPW) {
             const int d = hdec[j - 1];
             const bool ok = d >= 0 && is_img0 + (d >> 16) < a.N && (unsigned)(is_oy0 + ((d >> 8) & 255) - 1) < (unsigned)H &&
                             (unsigned)(is_ox0 + (d & 255) - 1) < (unsigned)W;
             const unsigned off = ok ? (unsigned)(is_xorg + hrel[j - 1]) : kOob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void_t *)(smem + sbase + 8192 + (wid + 8 * (j - 1)) * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void_t *)(smem + slot_i * XBYTES + (wid + 8 * (j - 1)) * 1024), 16, off, 0, 0, 0);
         }
     };
     auto issue = [&](auto slot_tag) __attribute__((always_inline)) {   // a whole patch at once (the first NS - 1)
@@ -174,6 +179,12 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     // 16-lane group addresses pixel row q (4 rows per read), channels 4pp..4pp+3 of the fragment's 16,
     // and receives the 4 pixels of channel (lane & 15).
     const int q = (lane & 15) >> 2, pp = lane & 3, fq = lane >> 4;
+    // LDS read addresses as pointers in VGPRs: a slot's stage base is a compile-time offset that folds into the read's
+    // 16-bit immediate, so one register set serves SPS = 64 KB / stage slots (the compiler, left alone, kept one set of
+    // 44 address registers PER SLOT: 132 of the kernel's 250 VGPRs at three slots, spills at four)
+    constexpr int SPS = 65536 / XBYTES, NSETS = (NS + SPS - 1) / SPS;   // x slots per address-register set
+    const lds_u8 *const smem_l = (const lds_u8 *)smem;
+    const lds_u8 *dyp[2][2][2], *xp[NSETS][2][2][9];   // [k-step][lo/hi 4-pixel group][dy fragment] / [set][k-step][lo/hi][tap]
     int dya[2][2], xa[2][2][9];                             // [k-step][lo/hi 4-pixel group]([tap]); dy fragment 1 = ^ 64
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -186,12 +197,20 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
             for (int tap = 0; tap < 9; ++tap) {
                 const int r = (tap * 11) >> 5, s = tap - 3 * r;
                 const int line = ti * p.HH + ty + r, hx = tx + s;
-                xa[ks][hi][tap] = 8192 + (line * p.HWP + hx) * 128 + ((wave_c ^ xkey(p.TW, line, hx)) & 3) * 32 + pp * 8;
+                xa[ks][hi][tap] = (line * p.HWP + hx) * 128 + ((wave_c ^ xkey(p.TW, line, hx)) & 3) * 32 + pp * 8;
                 // pin the value: left alone the compiler re-derives all 36 addresses inside the patch loop
                 // (~460 VALU instructions per patch) instead of keeping them in registers
-                asm volatile("" : "+v"(xa[ks][hi][tap]));
+#pragma unroll
+                for (int set = 0; set < NSETS; ++set) {
+                    xp[set][ks][hi][tap] = smem_l + set * SPS * XBYTES + xa[ks][hi][tap];
+                    asm volatile("" : "+v"(xp[set][ks][hi][tap]));
+                }
             }
-            asm volatile("" : "+v"(dya[ks][hi]));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                dyp[ks][hi][i] = smem_l + DYBASE + (dya[ks][hi] ^ (i * 64));
+                asm volatile("" : "+v"(dyp[ks][hi][i]));
+            }
         }
 
     f32x4_t acc[9][2];
@@ -202,10 +221,11 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
 
     // ---- MFMAs of one staged patch: 9 taps x 2 k-steps x 2 dy fragments.  The dy fragments of both
     // k-steps are read once per patch; the x fragments of tap t+1 are in flight while tap t's MFMAs run.
-    auto x_frags = [&](bf16x8_t (&fx)[2], const unsigned char *st, auto tap_tag) __attribute__((always_inline)) {   // st: compile-time stage base
-        constexpr int tap = decltype(tap_tag)::value;
+    auto x_frags = [&](bf16x8_t (&fx)[2], auto slot_tag, auto tap_tag) __attribute__((always_inline)) {
+        constexpr int tap = decltype(tap_tag)::value, slot = decltype(slot_tag)::value;
+        constexpr int set = slot / SPS, imm = (slot % SPS) * XBYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fx[ks] = join8(tr16d(st + xa[ks][0][tap]), tr16d(st + xa[ks][1][tap]));
+        for (int ks = 0; ks < 2; ++ks) fx[ks] = join8(tr16d(xp[set][ks][0][tap] + imm), tr16d(xp[set][ks][1][tap] + imm));
         __builtin_amdgcn_sched_barrier(0);
     };
     auto mfma_tap = [&](auto tap_tag, const bf16x8_t (&fk)[2][2], const bf16x8_t (&fx)[2]) __attribute__((always_inline)) {
@@ -218,13 +238,13 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         __builtin_amdgcn_sched_barrier(0);
     };
     auto compute = [&](auto slot_tag, auto nslot_tag, bool ahead) __attribute__((always_inline)) {
-        const unsigned char *st = smem + decltype(slot_tag)::value * stage_bytes;   // folds into the reads' immediates
+        constexpr int slot = decltype(slot_tag)::value, imm = slot * DYBYTES;
         bf16x8_t fk[2][2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                fk[ks][i] = join8(tr16d(st + (dya[ks][0] ^ (i * 64))), tr16d(st + (dya[ks][1] ^ (i * 64))));
+                fk[ks][i] = join8(tr16d(dyp[ks][0][i] + imm), tr16d(dyp[ks][1][i] + imm));
         using std::integral_constant;
         // tap t: fragments of tap t + 1 -> other register set | MFMAs of tap t
         // (tried: one DMA piece of patch i + NS - 1 behind every second tap block instead of all of them in front of
@@ -235,9 +255,9 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         (void)nslot_tag;
         (void)ahead;
         bf16x8_t fx0[2], fx1[2];
-        x_frags(fx0, st, integral_constant<int, 0>{});
+        x_frags(fx0, slot_tag, integral_constant<int, 0>{});
 #define COMBAT_W3_TAP(t, cur, nxt)                                                   \
-        if (t < 8) x_frags(nxt, st, integral_constant<int, (t < 8 ? t + 1 : 8)>{});  \
+        if (t < 8) x_frags(nxt, slot_tag, integral_constant<int, (t < 8 ? t + 1 : 8)>{});  \
         mfma_tap(integral_constant<int, t>{}, fk, cur);
         COMBAT_W3_TAP(0, fx0, fx1) COMBAT_W3_TAP(1, fx1, fx0) COMBAT_W3_TAP(2, fx0, fx1) COMBAT_W3_TAP(3, fx1, fx0)
         COMBAT_W3_TAP(4, fx0, fx1) COMBAT_W3_TAP(5, fx1, fx0) COMBAT_W3_TAP(6, fx0, fx1) COMBAT_W3_TAP(7, fx1, fx0)
@@ -253,11 +273,13 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     // everything younger (NS - 2 patches) may stay in flight.
     const int npatch = t_end - t_begin;
     using std::integral_constant;
+    unsigned long long ph[4] = {0, 0, 0, 0};
+    unsigned long long c_loop0 = 0;
+    {
     issue(integral_constant<int, 0>{});
     if (NS > 2 && npatch > 1) issue(integral_constant<int, 1 % NS>{});
     if (NS > 2 && npatch > 1) wait_vm_lgkm0_barrier<NDMA>(); else wait_vm_lgkm0_barrier<0>();
-    unsigned long long ph[4] = {0, 0, 0, 0};
-    const unsigned long long c_loop0 = WCLK();
+    c_loop0 = WCLK();
     auto body = [&](auto slot_tag, int i) __attribute__((always_inline)) {
         constexpr int slot = decltype(slot_tag)::value, nslot = (slot + NS - 1) % NS;
         const bool ahead = i + NS - 1 < npatch;
@@ -279,6 +301,7 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         body(integral_constant<int, 0>{}, i);
         if (NS > 1 && i + 1 < npatch) body(integral_constant<int, 1 % NS>{}, i + 1);
         if (NS > 2 && i + 2 < npatch) body(integral_constant<int, 2 % NS>{}, i + 2);
+    }
     }
     static_assert(NS == 2 || NS == 3, "the patch loop is unrolled for rings of two or three stages");
 #ifdef COMBAT_STAMPS
@@ -332,8 +355,8 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         }
     }
 #ifdef COMBAT_STAMPS
-    if (tid == 0 && p.stamps) {
-        unsigned long long *o = p.stamps + blockIdx.x * 8;
+    if (lane == 0 && p.stamps) {     // one record per wave
+        unsigned long long *o = p.stamps + (blockIdx.x * 8 + wid) * 8;
         o[0] = ph[0]; o[1] = ph[1]; o[2] = ph[2]; o[3] = ph[3];
         o[4] = c_loop1 - c_loop0; o[5] = WCLK() - c_loop1; o[6] = c_loop0;
     }
@@ -476,7 +499,7 @@ int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st) {
     const int blocks = base * p.split;
     int rc;
     if (p.hpw == 2) rc = launch_w3d<2, 3>(p, blocks, st);        // 3 x 24 KB
-    else if (p.hpw == 3) rc = launch_w3d<3, 2>(p, blocks, st);   // 2 x 32 KB (ds_read immediates reach 64 KB)
+    else if (p.hpw == 3) rc = launch_w3d<3, 2>(p, blocks, st);   // 2 x 32 KB
     else rc = launch_w3d<4, 2>(p, blocks, st);                   // 2 x 40 KB
     if (rc != COMBAT_OK || !p.ws) return rc;
     // enough workgroups to fill the chip; each group of ranges costs one fp32 atomic per element

@@ -40,7 +40,10 @@ class Plan:
         self.calls: List[Tuple] = []
         self._keep: List = []
         self.marks: Dict[int, int] = {}   # call index -> flat-gradient offset complete after that call
-        self.aux: set = set()             # indices of calls that may run on the auxiliary stream
+        self.aux: Dict[int, int] = {}     # call index -> auxiliary queue of the calls that may run beside the plan's own stream
+        self.aux_queues = 1               # auxiliary queues the aux calls are dealt to, round-robin (each with its own
+        #                                   weight-gradient scratch).  Measured: 2 for the generator's backward 4.19 -> 4.23
+        #                                   ms/step, 2 for the surrogate's 4.14 -> 4.17: one queue it stays
         self.wgrads: List[Tuple] = []     # (call index, WgradArgs) of the weight-gradient launches
         self._ws = None
 
@@ -49,7 +52,11 @@ class Plan:
         all-reduce), so it may run on the auxiliary stream beside the calls that follow it."""
         self.calls.append((cfunc, args, what))
         if aux:
-            self.aux.add(len(self.calls) - 1)
+            self.aux[len(self.calls) - 1] = self.next_aux_queue()
+
+    def next_aux_queue(self) -> int:
+        """Queue the next aux call will be given (round-robin over `aux_queues`)."""
+        return len(self.aux) % self.aux_queues
 
     def hold(self, *objs) -> None:
         self._keep.extend(objs)
@@ -73,8 +80,10 @@ class Plan:
         has been enqueued (data-parallel bucketed all-reduce overlapping the rest of the backward)."""
         stream = torch.cuda.current_stream()
         st = stream.cuda_stream
-        aux = _aux_stream(stream) if self.aux and not Plan.serial else None
-        aux_used = False
+        auxs = []
+        if self.aux and not Plan.serial:
+            auxs = [_aux_stream(stream, k) for k in range(self.aux_queues)]
+        used = set()
         for ci, (cfunc, args, what) in enumerate(self.calls):
             if prof is not None and (cfunc is lib.combat_conv_gemm or cfunc is lib.combat_conv_wgrad):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -82,27 +91,28 @@ class Plan:
                 rc = cfunc(*args, st)
                 e1.record(stream)
                 prof.append((self.name + "/" + what, args[0]._obj, e0, e1))
-            elif aux is not None and ci in self.aux:
+            elif auxs and ci in self.aux:
                 # everything enqueued so far (the producers of this call's operands) happens-before it
+                q = self.aux[ci]
                 ev = torch.cuda.Event()
                 ev.record(stream)
-                aux.wait_event(ev)
-                rc = cfunc(*args, aux.cuda_stream)
-                aux_used = True
+                auxs[q].wait_event(ev)
+                rc = cfunc(*args, auxs[q].cuda_stream)
+                used.add(q)
             else:
                 rc = cfunc(*args, st)
             if rc:
                 kind = {-1: "invalid shape/argument", -2: "HIP launch failed"}.get(rc, "status %d" % rc)
                 raise CombatHipError("%s/%s: %s" % (self.name, what, kind))
             if on_mark is not None and ci in self.marks:
-                if aux_used:   # the gradients above the mark include auxiliary-stream results
+                for q in used:   # the gradients above the mark include auxiliary-stream results
                     ev = torch.cuda.Event()
-                    ev.record(aux)
+                    ev.record(auxs[q])
                     stream.wait_event(ev)
                 on_mark(self.marks[ci])
-        if aux_used:           # join: whoever runs after the plan sees every result
+        for q in used:           # join: whoever runs after the plan sees every result
             ev = torch.cuda.Event()
-            ev.record(aux)
+            ev.record(auxs[q])
             stream.wait_event(ev)
 
     def __len__(self):
@@ -112,13 +122,13 @@ class Plan:
 _AUX_STREAMS: Dict = {}
 
 
-def _aux_stream(parent: torch.cuda.Stream) -> torch.cuda.Stream:
+def _aux_stream(parent: torch.cuda.Stream, k: int = 0) -> torch.cuda.Stream:
     """The auxiliary stream of the stream a plan runs on, for calls marked aux (weight gradients beside
     the input-gradient chain).  Per parent stream: two chains that run concurrently must not order each
     other through a shared auxiliary queue.  (Tried and dropped: a second auxiliary stream for the
     shortcut convolutions with a join in front of their consumer -- each cross-stream wait costs the
     critical path more than the 15 us convolution it hides: 5.63 -> 5.93 ms/step.)"""
-    key = (parent.device, parent.cuda_stream)
+    key = (parent.device, parent.cuda_stream, k)
     s = _AUX_STREAMS.get(key)
     if s is None:
         s = torch.cuda.Stream(device=parent.device)
@@ -282,7 +292,7 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
         a.pro_scale, a.pro_shift = _p(pro.scale), _p(pro.shift)
         a.pro_group_stride, a.pro_act, a.pro_slope = pro.group_stride, int(pro.act), pro.slope
     a.split = 0
-    ws = _wgrad_workspace(src.device, aux)
+    ws = _wgrad_workspace(src.device, plan.next_aux_queue() if aux else -1)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     plan.hold(a, src, dy, dw, pro, ws)
     plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a), aux=aux)
@@ -299,9 +309,9 @@ def balance_wgrads(plan: Plan, device) -> None:
     if tail <= 0 or Plan.serial:
         return
     aux_calls = [(ci, a) for ci, a in plan.wgrads if ci in plan.aux]
-    ws = _wgrad_workspace(device, False)
+    ws = _wgrad_workspace(device, -1)
     for ci, a in aux_calls[-tail:]:
-        plan.aux.discard(ci)
+        plan.aux.pop(ci, None)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
         plan.hold(ws)
 
@@ -312,14 +322,14 @@ WGRAD_MAIN_TAIL = 0
 _WGRAD_WS: Dict = {}
 
 
-def _wgrad_workspace(device, aux: bool = True) -> torch.Tensor:
+def _wgrad_workspace(device, queue: int = 0) -> torch.Tensor:
     """Scratch for the weight-gradient partial sums (pixel ranges x tiles <= ~256 + tiles slabs of 147 KB; a
     launch that would need more falls back to fp32 atomics by itself).  One buffer per device AND per queue
     the launch is recorded for: launches of one queue run one after the other, but the last weight gradient of
-    a backward plan (aux=False) runs on the plan's own stream while its predecessors may still be writing /
-    reducing their slabs on the auxiliary stream -- sharing one base pointer between the two queues let those
-    launches overwrite each other's partial sums."""
-    key = (device, bool(aux))
+    a backward plan (queue -1) runs on the plan's own stream while its predecessors may still be writing /
+    reducing their slabs on an auxiliary stream (queue 0, 1, ...) -- sharing one base pointer between two queues let
+    those launches overwrite each other's partial sums."""
+    key = (device, int(queue))
     ws = _WGRAD_WS.get(key)
     if ws is None:
         ws = torch.empty(48 << 20, dtype=torch.uint8, device=device)

@@ -1,0 +1,20 @@
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import bench
+from combat_amd import step as step_mod
+device = torch.device("cuda", 0)
+opt = bench.Opt()
+np.random.seed(0); torch.manual_seed(100)
+st = step_mod.AlternatedStep(*bench.build_nets(device), opt)
+batches = bench.synth_batches(8, opt.bs, 0, device)
+import contextlib
+hp = torch.cuda.Stream(priority=-1) if os.environ.get("QS_HIPRI") else None
+ctx = torch.cuda.stream(hp) if hp is not None else contextlib.nullcontext()
+ctx.__enter__()
+for i in range(10): st.run(*batches[i % 8])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+N = 60
+for i in range(N): st.run(*batches[i % 8])
+torch.cuda.synchronize()
+print("%-40s %.3f ms/step" % (" ".join("%s=%s" % (k[11:] if k.startswith("COMBAT_EXP_") else k, v) for k, v in sorted(os.environ.items()) if k.startswith("COMBAT_EXP_") or k.startswith("QS_")) or "-", (time.perf_counter() - t0) / N * 1e3))

@@ -20,14 +20,19 @@ for name, n, hw, c, k in [("L1", 128, 32, 64, 64), ("L2", 128, 16, 128, 128), ("
         if cold:
             flush.fill_(1)
         torch.cuda.synchronize()
-        st = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda")
+        st = torch.zeros(8 * 4096 * 8, dtype=torch.int64, device="cuda")
         lib.combat_debug_set_stamps_wgrad(ctypes.c_void_p(st.data_ptr()))
         ops.conv_wgrad(x, dy, pc, dw, workspace=ws)
         torch.cuda.synchronize()
         lib.combat_debug_set_stamps_wgrad(ctypes.c_void_p(0))
         s = st.cpu().numpy().reshape(-1, 8)
-        s = s[s[:, 3] > 0].astype(np.float64)
+        nwg = int((s[:, 3] > 0).sum()) // 8
+        per_wave = s[: nwg * 8].reshape(nwg, 8, 8).astype(np.float64)
+        print("   per wave id (issue / compute / wait): " + "  ".join(
+            "%d:%.0f/%.0f/%.0f" % (w, (per_wave[:, w, 0] / per_wave[:, w, 3]).mean(), (per_wave[:, w, 1] / per_wave[:, w, 3]).mean(),
+                                   (per_wave[:, w, 2] / per_wave[:, w, 3]).mean()) for w in range(8)))
+        s = per_wave[:, 0, :]
         npatch = s[:, 3].mean()
-        print("%s %s: %d workgroups, %.1f patches each | per patch: issue %.0f  compute %.0f  wait+barrier %.0f cyc | loop %.0f  epilogue %.0f cyc"
+        print("%s %s: %d workgroups (wave 0), %.1f patches each | per patch: issue %.0f  compute %.0f  wait+barrier %.0f cyc | loop %.0f  epilogue %.0f cyc"
               % (name, "cold" if cold else "warm", len(s), npatch, (s[:, 0] / s[:, 3]).mean(), (s[:, 1] / s[:, 3]).mean(),
                  (s[:, 2] / s[:, 3]).mean(), s[:, 4].mean(), s[:, 5].mean()), flush=True)
