@@ -270,6 +270,24 @@ __global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs 
     const int tid = threadIdx.x, co = tid & 7, pl = tid >> 3;
     const int c = blockIdx.x * 64 + co * 8, chunk = blockIdx.y, g = blockIdx.z;
     const bool live = c < a.C;
+    // The first pass of this workgroup's chunk is loaded BEFORE the statistics are reduced: the two do not depend on
+    // each other, and in a launch whose workgroups all run at once (<= 1024 of them) the row reduction's round trip and
+    // the tensor's would otherwise follow one another -- 2 of a 10-us launch.
+    constexpr int NB = 8;
+    const long i0 = (long)chunk * a.chunk_px;
+    long i1 = i0 + a.chunk_px;
+    if (i1 > a.pxg) i1 = a.pxg;
+    u32x4_t lx[NB], la[NB];
+    auto load_pass = [&](long ib) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const long i = ib + 32 * q;
+            const long off = ((long)g * a.pxg + (i < i1 ? i : i1 - 1)) * a.C + c;
+            lx[q] = *reinterpret_cast<const u32x4_t *>(a.x + off);
+            if (a.add) la[q] = *reinterpret_cast<const u32x4_t *>(a.add + off);
+        }
+    };
+    if (live && i0 + pl < i1) load_pass(i0 + pl);
     double s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.0;
@@ -345,9 +363,6 @@ __global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs 
         sh[e] = coef[1][co * 8 + e];
     }
     if (!live) return;
-    const long i0 = (long)chunk * a.chunk_px;
-    long i1 = i0 + a.chunk_px;
-    if (i1 > a.pxg) i1 = a.pxg;
     float asc[8], ash[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -362,16 +377,8 @@ __global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs 
     // load -> arithmetic -> store loop every iteration waited out its own load (x and act may alias for all the
     // compiler knows, so it keeps the order) -- eight exposed round trips to HBM per thread for a 256-pixel chunk,
     // most of the launch's 10 us.
-    constexpr int NB = 8;
     for (long ib = i0 + pl; ib < i1; ib += 32 * NB) {
-        u32x4_t lx[NB], la[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const long i = ib + 32 * q;
-            const long off = ((long)g * a.pxg + (i < i1 ? i : i1 - 1)) * a.C + c;
-            lx[q] = *reinterpret_cast<const u32x4_t *>(a.x + off);
-            if (a.add) la[q] = *reinterpret_cast<const u32x4_t *>(a.add + off);
-        }
+        if (ib != i0 + pl) load_pass(ib);
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const long i = ib + 32 * q;
@@ -410,6 +417,22 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const FusedBwdArgs 
     const int tid = threadIdx.x, co = tid & 7, pl = tid >> 3;
     const int c = blockIdx.x * 64 + co * 8, chunk = blockIdx.y, g = blockIdx.z;
     const bool live = c < a.C;
+    constexpr int NB = 8;   // (first pass loaded before the statistics, all of a pass's loads before its first use: see norm_act_fused_kernel)
+    const long i0 = (long)chunk * a.chunk_px;
+    long i1 = i0 + a.chunk_px;
+    if (i1 > a.pxg) i1 = a.pxg;
+    u32x4_t ld[NB], lx[NB], la[NB];
+    auto load_pass = [&](long ib) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const long i = ib + 32 * q;
+            const long off = ((long)g * a.pxg + (i < i1 ? i : i1 - 1)) * a.C + c;
+            ld[q] = *reinterpret_cast<const u32x4_t *>(a.dz + off);
+            lx[q] = *reinterpret_cast<const u32x4_t *>(a.x + off);
+            if (a.add) la[q] = *reinterpret_cast<const u32x4_t *>(a.add + off);
+        }
+    };
+    if (live && i0 + pl < i1) load_pass(i0 + pl);
     double s1[8], s2[8];
     float mu[8], rs[8];
 #pragma unroll
@@ -483,20 +506,8 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const FusedBwdArgs 
         kc[e] = coef[2][co * 8 + e];
     }
     if (!live) return;
-    const long i0 = (long)chunk * a.chunk_px;
-    long i1 = i0 + a.chunk_px;
-    if (i1 > a.pxg) i1 = a.pxg;
-    constexpr int NB = 8;   // (all of a pass's loads before its first use: see norm_act_fused_kernel)
     for (long ib = i0 + pl; ib < i1; ib += 32 * NB) {
-        u32x4_t ld[NB], lx[NB], la[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) {
-            const long i = ib + 32 * q;
-            const long off = ((long)g * a.pxg + (i < i1 ? i : i1 - 1)) * a.C + c;
-            ld[q] = *reinterpret_cast<const u32x4_t *>(a.dz + off);
-            lx[q] = *reinterpret_cast<const u32x4_t *>(a.x + off);
-            if (a.add) la[q] = *reinterpret_cast<const u32x4_t *>(a.add + off);
-        }
+        if (ib != i0 + pl) load_pass(ib);
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const long i = ib + 32 * q;

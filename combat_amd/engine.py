@@ -34,6 +34,7 @@ class Plan:
     """An ordered list of C-ABI calls with pre-marshalled arguments (stream appended at run)."""
 
     serial = False   # True: auxiliary-stream calls run in line (kernel-level measurements: one kernel at a time)
+    default_aux_queues = 1   # auxiliary queues a new plan deals its aux calls to (see aux_queues below)
 
     def __init__(self, name: str):
         self.name = name
@@ -41,7 +42,7 @@ class Plan:
         self._keep: List = []
         self.marks: Dict[int, int] = {}   # call index -> flat-gradient offset complete after that call
         self.aux: Dict[int, int] = {}     # call index -> auxiliary queue of the calls that may run beside the plan's own stream
-        self.aux_queues = 1               # auxiliary queues the aux calls are dealt to, round-robin (each with its own
+        self.aux_queues = Plan.default_aux_queues   # auxiliary queues the aux calls are dealt to, round-robin (each with its own
         #                                   weight-gradient scratch).  Measured: 2 for the generator's backward 4.19 -> 4.23
         #                                   ms/step, 2 for the surrogate's 4.14 -> 4.17: one queue it stays
         self.wgrads: List[Tuple] = []     # (call index, WgradArgs) of the weight-gradient launches

@@ -530,6 +530,22 @@ def test_backward_plans_do_not_share_weight_gradient_scratch(mods):
         got = grads(eg.fp, gnames, gb.run)
         for k in gnames:
             assert rel_l2(got[k], ref[k]) < 1e-5 or float(ref[k].abs().max()) == 0.0, ("unet", rep, k, rel_l2(got[k], ref[k]))
+    # ---- the same plan dealt to TWO auxiliary queues (each queue has its own scratch): weight gradients of
+    # neighbouring layers then run concurrently
+    engine.Plan.default_aux_queues = 2
+    try:
+        sg2 = eg.slot("race2", 128, 32)
+        ops.image_to_c8(x.cuda(), eg.input(sg2))
+        eg.forward_plan(sg2).run()
+        sg2.buf("g.z", (128, 32, 32, 8)).copy_(z)
+        gb2 = eg.backward_plan(sg2)
+        assert gb2.aux_queues == 2 and set(gb2.aux.values()) == {0, 1}
+        for rep in range(3):
+            got = grads(eg.fp, gnames, gb2.run)
+            for k in gnames:
+                assert rel_l2(got[k], ref[k]) < 1e-5 or float(ref[k].abs().max()) == 0.0, ("unet 2 queues", rep, k, rel_l2(got[k], ref[k]))
+    finally:
+        engine.Plan.default_aux_queues = 1
 
 
 def _ema(v, a=0.1):

@@ -115,9 +115,11 @@ def main():
         if a == "--tiles":
             tiles = [int(v) for v in sys.argv[i + 1].split(",")]
     ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    n_over = int(os.environ.get("CB_N", 0))      # batch override (what a half-batch chain would pay per launch)
     for name, n, hw, c, k, stride in SHAPES:
         if sel and not any(s in name for s in sel):
             continue
+        n = n_over or n
         gf = 2.0 * n * (hw // stride) ** 2 * c * k * 9 / 1e9
         for mode in ("fwd_train", "fwd_eval", "dgrad"):
             cells = []

@@ -4,6 +4,7 @@ import bench
 from combat_amd import step as step_mod
 device = torch.device("cuda", 0)
 opt = bench.Opt()
+opt.bs = int(os.environ.get("QS_BS", opt.bs))
 np.random.seed(0); torch.manual_seed(100)
 st = step_mod.AlternatedStep(*bench.build_nets(device), opt)
 batches = bench.synth_batches(8, opt.bs, 0, device)
@@ -15,6 +16,14 @@ for i in range(10): st.run(*batches[i % 8])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 N = 60
-for i in range(N): st.run(*batches[i % 8])
+host = 0.0
+for i in range(N):
+    h0 = time.perf_counter()
+    st.run(*batches[i % 8])
+    host += time.perf_counter() - h0
+t_host_done = time.perf_counter()
 torch.cuda.synchronize()
-print("%-40s %.3f ms/step" % (" ".join("%s=%s" % (k[11:] if k.startswith("COMBAT_EXP_") else k, v) for k, v in sorted(os.environ.items()) if k.startswith("COMBAT_EXP_") or k.startswith("QS_")) or "-", (time.perf_counter() - t0) / N * 1e3))
+from combat_amd.engine import Plan
+nd = getattr(Plan, "_ndelay", 0) / (N + 10)
+print("delay launches/step %.1f" % nd)
+print("%-40s %.3f ms/step" % (" ".join("%s=%s" % (k[11:] if k.startswith("COMBAT_EXP_") else k, v) for k, v in sorted(os.environ.items()) if k.startswith("COMBAT_EXP_") or k.startswith("QS_")) or "-", (time.perf_counter() - t0) / N * 1e3), " host in run() %.3f ms/step, host loop done after %.3f ms/step" % (host / N * 1e3, (t_host_done - t0) / N * 1e3))
