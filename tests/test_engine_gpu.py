@@ -702,6 +702,11 @@ def test_alternated_step_runs_with_sampled_randomness_and_empty_poison(mods):
     assert all(np.isfinite(v) for v in m.values())
     for p in list(netc.parameters()) + list(netg.parameters()):
         assert torch.isfinite(p).all()
+    # streams are process-wide, not per step object (a second object must not add hardware queues: see step.shared_stream)
+    st2 = step_mod.AlternatedStep(netc, netg, clean, netf, opt)
+    st2.run(x.cuda(), t)
+    torch.cuda.synchronize()
+    assert st2._main is st._main and st2._side is st._side and st._main is not None
 
 
 def test_classifier_step_metrics_cover_ragged_batches(mods):
