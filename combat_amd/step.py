@@ -252,11 +252,14 @@ class AlternatedStep:
         """inputs: float32 [B,3,H,W] (device or pinned host); targets_cpu: int64 [B] on the host,
         as the DataLoader yields them (train_generator.py:170-171).
 
-        The step's critical chain runs on a HIGH-PRIORITY stream of its own (the second stream and the auxiliary
-        weight-gradient queues keep the default priority): when workgroup slots free up the dispatcher then serves
-        the critical queue first (4.18 -> 4.15 ms/step on one box).  The caller's stream is joined on both sides, so
-        from outside the step still behaves like work enqueued on the current stream."""
-        if self.serial:
+        The step runs on the caller's stream plus two process-wide ones (second stream, auxiliary weight-gradient
+        queue).  COMBAT_OWN_STREAM=1 moves the critical chain to a high-priority stream of its own (joined with the
+        caller's on both sides): 4.18 -> 4.15 ms/step on a quiet process, but the HIP runtime multiplexes a process's
+        streams onto few hardware queues and a high-priority stream makes that mapping fragile -- ONE more stream in
+        use anywhere in the process (a collective library's, a second step object's) and launches block on the host:
+        7-11 ms/step measured.  Without it the step tolerates four foreign streams (4.28-4.33 ms/step; 5.4 at six).
+        Off by default for that reason."""
+        if self.serial or os.environ.get("COMBAT_OWN_STREAM", "0") != "1":
             return self._run(inputs, targets_cpu, rnd, lr_c, lr_g, prof)
         caller = torch.cuda.current_stream()
         if self._main is None:

@@ -9,6 +9,11 @@ np.random.seed(0); torch.manual_seed(100)
 st = step_mod.AlternatedStep(*bench.build_nets(device), opt)
 batches = bench.synth_batches(8, opt.bs, 0, device)
 import contextlib
+extra = [torch.cuda.Stream(priority=(-1 if os.environ.get("QS_EXTRA_HP") else 0)) for _ in range(int(os.environ.get("QS_EXTRA_STREAMS", 0)))]
+for e in extra:      # a stream only takes a hardware queue once it has been used
+    with torch.cuda.stream(e):
+        torch.zeros(4, device="cuda").add_(1)
+torch.cuda.synchronize()
 hp = torch.cuda.Stream(priority=-1) if os.environ.get("QS_HIPRI") else None
 ctx = torch.cuda.stream(hp) if hp is not None else contextlib.nullcontext()
 ctx.__enter__()
