@@ -133,17 +133,50 @@ class ArrayLoader:
             order = torch.cat([order, order[: total - n]])
         return order[self.rank::self.world]
 
+    RING = 8    # pinned staging buffers (batches the host may be ahead of the device's copies)
+
+    def _staging(self):
+        """A ring of pinned float batches, allocated once.  (`tensor.pin_memory()` per batch cost 18 ms each on the
+        MI355X box -- a fresh page-locked allocation whenever the device is behind -- and turned a 4.2-ms step into a
+        28-ms one.)  A slot is rewritten only after the event recorded behind its consumer's work has completed."""
+        if getattr(self, "_ring", None) is None:
+            shape = (self.RING, self.bs) + tuple(self.x.shape[1:])
+            self._ring = torch.empty(shape, dtype=torch.float32).pin_memory()
+            self._ring_ev = [None] * self.RING
+            self._ring_i = 0
+        return self._ring
+
     def __iter__(self) -> Iterator:
         order = self.epoch_order(self.epoch)
         self.epoch += 1
+        cuda = torch.cuda.is_available()
+        x_np, half, c255 = self.x.numpy(), np.float32(0.5), np.float32(255.0)
         for i in range(len(self)):
             idx = order[i * self.bs:(i + 1) * self.bs]
-            xb = ((self.x[idx].float() / 255.0) - 0.5) / 0.5
-            xb = xb.pin_memory() if torch.cuda.is_available() else xb
+            if cuda:
+                ring = self._staging()
+                k = self._ring_i
+                self._ring_i = (k + 1) % self.RING
+                if self._ring_ev[k] is not None:
+                    self._ring_ev[k].synchronize()
+                xb = ring[k, : idx.numel()]
+            else:
+                xb = torch.empty((idx.numel(),) + tuple(self.x.shape[1:]), dtype=torch.float32)
+            # ToTensor + Normalize(0.5, 0.5) (utils/dataloader.py:35-39) in numpy: ONE thread.  torch's CPU kernels
+            # open an OpenMP region over every hardware thread the box shows (128 on the MI355X boxes, 16 of them
+            # usable): 1.8 ms for this 1.5-MB batch idle, ~18 ms beside the thread that drives the GPU.
+            out = xb.numpy()
+            np.divide(x_np[idx.numpy()], c255, out=out, dtype=np.float32)
+            np.subtract(out, half, out=out)
+            np.divide(out, half, out=out)
             if self.poisoned is None:
                 yield xb, self.y[idx]
             else:
                 yield xb, self.y[idx], self.poisoned[idx]
+            if cuda:    # the consumer has enqueued its copy of this batch by the time it asks for the next one
+                ev = torch.cuda.Event()
+                ev.record()
+                self._ring_ev[k] = ev
 
 
 def poison_flags(labels: np.ndarray, opt, n_classes: int) -> np.ndarray:

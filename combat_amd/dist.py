@@ -17,8 +17,19 @@ import torch
 import torch.distributed as dist
 
 
+def limit_host_threads() -> None:
+    """The host side of this package is one thread feeding the GPU plus batch-sized CPU tensor ops.  torch sizes its
+    intra-op pool to every hardware thread it sees (128 on the MI355X boxes, whatever the process may actually use),
+    and a 128-thread OpenMP region around a 1.5-MB operation costs milliseconds: cap it (COMBAT_HOST_THREADS, default
+    8 or the current setting if smaller)."""
+    want = int(os.environ.get("COMBAT_HOST_THREADS", 0)) or min(torch.get_num_threads(), 8)
+    if want != torch.get_num_threads():
+        torch.set_num_threads(want)
+
+
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """(rank, local_rank, world) from the torchrun environment; no-op for a single process."""
+    limit_host_threads()
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
     if world > 1 and not dist.is_initialized():

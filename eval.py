@@ -8,6 +8,7 @@ import torch
 
 import config
 from combat_amd import api
+from combat_amd import dist as cdist
 from combat_amd.data import get_dataloader
 from combat_amd.log import SummaryWriter, progress_bar
 from combat_amd.nets import UnetGenerator, configure_dataset, default_classifier
@@ -44,6 +45,7 @@ def eval(netC, netG, test_dl, tf_writer, opt):
 def main():
     opt = config.get_arguments().parse_args()
     configure_dataset(opt)
+    cdist.limit_host_threads()
     test_dl = get_dataloader(opt, False, shuffle=False)
     netC, netG = get_model(opt)
     mode = opt.saving_prefix

@@ -412,3 +412,20 @@ def test_data_parallel_gradient_exchange_gloo_world2(tmp_path):
     port = 29600 + os.getpid() % 300
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert open(tmp_path / "ok0").read() == "True" and open(tmp_path / "ok1").read() == "True"
+
+
+def test_loader_batches_equal_totensor_normalize_bit_for_bit():
+    """ArrayLoader converts in numpy (one thread, into a reused buffer on CUDA hosts): the batch must equal the
+    reference's ToTensor + Normalize(0.5, 0.5) chain (utils/dataloader.py:35-39) exactly, ragged last batch included,
+    and successive batches must not alias each other within the ring's depth."""
+    from combat_amd.data import ArrayLoader, synthetic_cifar10
+    x, y = synthetic_cifar10(300, 3, 32, 10)
+    ld = ArrayLoader(x, y, 128, True, base_seed=5)
+    order = ld.epoch_order(0)
+    got = [(xb.clone(), yb.clone(), xb) for xb, yb in ld]
+    assert [g[0].shape[0] for g in got] == [128, 128, 44]
+    for i, (xb, yb, _) in enumerate(got):
+        idx = order[i * 128:(i + 1) * 128]
+        ref = ((torch.from_numpy(x)[idx].float() / 255.0) - 0.5) / 0.5
+        assert torch.equal(xb, ref) and torch.equal(yb, torch.from_numpy(y)[idx])
+    assert got[0][2].data_ptr() != got[1][2].data_ptr()

@@ -9,6 +9,8 @@ np.random.seed(0); torch.manual_seed(100)
 st = step_mod.AlternatedStep(*bench.build_nets(device), opt)
 batches = bench.synth_batches(8, opt.bs, 0, device)
 import contextlib
+if os.environ.get("QS_THREADS"):
+    torch.set_num_threads(int(os.environ["QS_THREADS"]))
 extra = [torch.cuda.Stream(priority=(-1 if os.environ.get("QS_EXTRA_HP") else 0)) for _ in range(int(os.environ.get("QS_EXTRA_STREAMS", 0)))]
 for e in extra:      # a stream only takes a hardware queue once it has been used
     with torch.cuda.stream(e):

@@ -12,6 +12,7 @@ every rank a disjoint shard of each epoch and averages the gradients over RCCL (
 """
 import os
 import random
+import time
 
 import numpy as np
 import torch
@@ -246,9 +247,13 @@ def main(get_model=None, train=None, eval=None):
 
     for epoch in range(epoch_current, opt.n_iters):
         print("Epoch {}:".format(epoch + 1))
+        t0 = time.perf_counter()
         train(netC, optimizerC, schedulerC, netG, optimizerG, schedulerG, netF, clean_model, train_dl, tf_writer, epoch, opt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         best = list(eval(netC, optimizerC, schedulerC, netG, optimizerG, schedulerG, netF, clean_model, test_dl, *best,
                          tf_writer, epoch, opt))
+        print(" train {:.2f} s, eval + checkpoint {:.2f} s".format(t1 - t0, time.perf_counter() - t1))
 
 
 if __name__ == "__main__":
