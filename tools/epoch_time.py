@@ -20,9 +20,18 @@ def run(script, *args):
     return time.perf_counter() - t0, r.stdout
 
 
-run("train_clean_classifier.py", "--synthetic_size", "1280", "--saving_prefix", "classifier_clean", "--n_iters", "1")
+def epochs(out):
+    return "\n".join(l for l in out.replace("\r", "\n").splitlines() if "train " in l and " s, eval" in l)
+
+
+_, out = run("train_clean_classifier.py", "--synthetic_size", "25600", "--saving_prefix", "classifier_clean", "--n_iters", "3")
+print("train_clean_classifier.py (200 train + 200 eval batches per epoch):\n" + epochs(out))
 t1, _ = run("train_generator.py", "--synthetic_size", "25600", "--saving_prefix", "g1", "--load_checkpoint_clean", "classifier_clean", "--n_iters", "1")
 t3, out = run("train_generator.py", "--synthetic_size", "25600", "--saving_prefix", "g3", "--load_checkpoint_clean", "classifier_clean", "--n_iters", "3")
 per_epoch = (t3 - t1) / 2      # start-up (imports, first-launch set-up) cancels
 print("train_generator.py: %.2f s per epoch of 200 train + 200 eval batches of 128 (1 epoch %.1f s, 3 epochs %.1f s)" % (per_epoch, t1, t3))
-print("\n".join(l for l in out.replace("\r", "\n").splitlines() if "train " in l and " s, eval" in l))
+print(epochs(out))
+_, out = run("train_victim.py", "--synthetic_size", "25600", "--saving_prefix", "victim", "--load_checkpoint", "g3_clean", "--n_iters", "3")
+print("train_victim.py:\n" + epochs(out))
+_, out = run("train_generator_wanet.py", "--synthetic_size", "25600", "--saving_prefix", "w3", "--load_checkpoint_clean", "classifier_clean", "--n_iters", "2")
+print("train_generator_wanet.py:\n" + epochs(out))

@@ -2,6 +2,7 @@
 (reference train_clean_classifier.py:75-121 loop, :153-160 checkpoint keys, :191-193 path
 <checkpoints>/<saving_prefix>/<dataset>/<dataset>_<saving_prefix>.pth.tar)."""
 import os
+import time
 
 import torch
 
@@ -101,8 +102,12 @@ def main():
         tf_writer = cdist.NullWriter()
     for epoch in range(epoch_current, opt.n_iters):
         print("Epoch {}:".format(epoch + 1))
+        t0 = time.perf_counter()
         train(netC, optimizerC, schedulerC, train_dl, tf_writer, epoch, opt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         best = eval(netC, optimizerC, schedulerC, test_dl, best, tf_writer, epoch, opt)
+        print(" train {:.2f} s, eval + checkpoint {:.2f} s".format(t1 - t0, time.perf_counter() - t1))
 
 
 if __name__ == "__main__":

@@ -1,6 +1,7 @@
 """Victim training on data poisoned by the frozen generator (reference train_victim.py:93-165 loop,
 :168-231 eval, :221-229 checkpoint keys; dataset flags from utils/dataloader_cleanbd.py:131-158)."""
 import os
+import time
 
 import torch
 
@@ -124,9 +125,13 @@ def main():
         tf_writer = cdist.NullWriter()
     for epoch in range(epoch_current, opt.n_iters):
         print("Epoch {}:".format(epoch + 1))
+        t0 = time.perf_counter()
         train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         best_clean_acc, best_bd_acc = eval(netC, optimizerC, schedulerC, netG, test_dl, best_clean_acc, best_bd_acc,
                                            tf_writer, epoch, opt)
+        print(" train {:.2f} s, eval + checkpoint {:.2f} s".format(t1 - t0, time.perf_counter() - t1))
 
 
 if __name__ == "__main__":
