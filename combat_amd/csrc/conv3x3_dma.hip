@@ -43,6 +43,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 //   COMBAT_ABL_NOMFMA  the MFMA blocks become one VALU op per fragment pair (fragment reads stay alive)
 //   COMBAT_ABL_NODMA   no weight / halo DMA after the first halo patch (the counted waits shrink accordingly)
 //   COMBAT_ABL_NOREAD  no LDS fragment reads (the MFMAs run on whatever the registers hold)
+//   COMBAT_ABL_NOEPI   no epilogue (operand fetches still issued; nothing is stored)
 #if defined(COMBAT_ABL_NODMA)
 #define ABL_DMA(x) 0
 #else
@@ -390,7 +391,18 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     // wave has passed the barrier) -> row-major items
     if constexpr (!WIDE) {
         block_barrier();
+#ifdef COMBAT_ABL_NOEPI     // (ablation: one store per lane keeps the accumulators alive)
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FM; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (s == 12345.678f) reinterpret_cast<float *>(const_cast<void *>(a.dst))[lane] = s;
+        }
+#else
         epi_finish<TE>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged, p.PQ, p.flavour);
+#endif
     } else {
         // two 32-pixel halves, one after the other (both halves' operand sets at once would be 136 registers on
         // top of the 64 accumulators); the first half's fetches go out before the barrier that frees the operand images
