@@ -376,6 +376,90 @@ def golden_trajectory_lr2e3():
     golden_trajectory(2e-3, "trajectory_lr2e3.npz")
 
 
+def golden_wanet_trajectory():
+    """60 alternated WaNet steps (train_generator_wanet.py:132-237) at B = 32 over a pool of 15 fixed batches,
+    lr 2e-3 (the smooth regime: see golden_trajectory_lr2e3), no augmentation, recorded num_bd: loss / counter curves
+    and the generator head after the last step, through the reference modules + torch.optim.SGD."""
+    out = {}
+
+    class WOpt:
+        s = 2
+
+    steps, b, POOL, lr = 60, 32, 15, 2e-3
+    pool = [(synth_images(b, 32, 9800 + i), torch.randint(0, 10, (b,), generator=rng(9900 + i))) for i in range(POOL)]
+    g = np.random.default_rng(77)
+    num_bds = [int((g.random(int((pool[s % POOL][1] == 0).sum())) < 0.5).sum()) for s in range(steps)]
+    torch.manual_seed(0)
+    netc = PreActResNet18()
+    torch.manual_seed(1)
+    clean = PreActResNet18().eval()
+    torch.manual_seed(2)
+    netg = GridGenerator(WOpt())
+    torch.manual_seed(3)
+    netf = FrequencyModel(num_classes=2, n_input=3, input_size=32).eval()
+    out["seeds"], out["pool_seeds"], out["pool"], out["lr"] = np.array([0, 1, 2, 3]), np.array([9800, 9900]), np.int64(POOL), np.float64(lr)
+    out["num_bd"] = np.array(num_bds)
+    opt_c = torch.optim.SGD(netc.parameters(), lr, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    opt_g = torch.optim.SGD(netg.parameters(), lr, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    keys = ("loss_c", "loss_ce", "loss_l2", "loss_grad_l2", "clean_model_loss", "clean_correct", "bd_correct", "f_correct",
+            "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr", "field")
+    trace = {k: [] for k in keys}
+    ce = torch.nn.CrossEntropyLoss()
+    for s in range(steps):
+        inputs, targets = pool[s % POOL]
+        bd_targets = torch.zeros_like(targets)
+        netg.eval(); clean.eval(); netc.train(); opt_c.zero_grad()
+        trg = (targets == bd_targets).nonzero()[:, 0]
+        ntrg = (targets != bd_targets).nonzero()[:, 0]
+        nb = num_bds[s]
+        chg = inputs[trg[:nb]]
+        if nb:
+            ibd, _ = _wanet_warp(chg, netg(chg))
+        else:
+            ibd = chg
+        tot_in = torch.cat([ibd, inputs[trg[nb:]], inputs[ntrg]], 0)
+        tot_t = torch.cat([bd_targets[trg[:nb]], targets[trg[nb:]], targets[ntrg]], 0)
+        loss_c = ce(netc(tot_in), tot_t)
+        loss_c.backward()
+        opt_c.step()
+        with torch.no_grad():
+            clean_preds = clean(inputs)
+        netc.eval(); netg.train(); opt_g.zero_grad()
+        field = netg(inputs)
+        ibd, ng = _wanet_warp(inputs, field)
+        with torch.no_grad():
+            pred_clean = netc(inputs)
+        pred_bd = netc(ibd)
+        loss_ce = ce(pred_bd, bd_targets)
+        loss_l2 = F.mse_loss(ng, ng * 0)
+        e, eb = F.pad(ng, (1, 1, 2, 1)), F.pad(ng * 0, (1, 1, 2, 1))
+        loss_grad_l2 = F.mse_loss(e[:, :, 1:] - e[:, :, :-1], eb[:, :, 1:] - eb[:, :, :-1]) + \
+            F.mse_loss(e[:, :, :, 1:] - e[:, :, :, :-1], eb[:, :, :, 1:] - eb[:, :, :, :-1])
+        with torch.no_grad():
+            pred_f = netf(ref_dct.dct_2d(((ibd + 1) / 2 * 255).byte()))
+        cm_preds = clean(ibd)
+        cm_loss = ce(cm_preds, targets)
+        (loss_ce + 0.02 * loss_l2 + 0.8 * cm_loss).backward()
+        opt_g.step()
+        for k, v in (("loss_c", loss_c), ("loss_ce", loss_ce), ("loss_l2", loss_l2), ("loss_grad_l2", loss_grad_l2),
+                     ("clean_model_loss", cm_loss)):
+            trace[k].append(float(v))
+        trace["field"].append(field[0].detach().flatten().numpy().copy())
+        trace["clean_correct"].append(int((pred_clean.argmax(1) == targets).sum()))
+        trace["bd_correct"].append(int((pred_bd.argmax(1) == bd_targets).sum()))
+        trace["f_correct"].append(int((pred_f.argmax(1) == 1).sum()))
+        trace["clean_model_correct"].append(int((clean_preds.argmax(1) == targets).sum()))
+        trace["clean_model_bd_ba"].append(int((cm_preds.argmax(1) == targets).sum()))
+        trace["clean_model_bd_asr"].append(int((cm_preds.argmax(1) == bd_targets).sum()))
+        if s % 10 == 9:
+            print("wanet trajectory step", s + 1, trace["loss_c"][-1], trace["loss_ce"][-1], flush=True)
+    for k, v in trace.items():
+        out["trace/" + k] = np.array(v, dtype=np.float64)
+    for k in ("fc1.bias", "fc2.weight", "fc2.bias"):
+        out["final/" + k] = dict(netg.named_parameters())[k].detach().numpy().copy()
+    save("wanet_trajectory.npz", out)
+
+
 def randomize_bn_buffers(net, seed):
     """Non-trivial BatchNorm running statistics for eval-mode fixtures, reproducible from the seed alone (the
     tests apply the same calls to combat_amd's mirror modules: same module order)."""

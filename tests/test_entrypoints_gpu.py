@@ -102,6 +102,22 @@ def test_wanet_workflow_on_synthetic_data(tmp_path):
     assert "Continue training!!" in out
 
 
+def test_wanet_celeba_workflow_on_synthetic_data(tmp_path):
+    """train_generator_wanet.py --dataset celeba (reference :63-66: 64 x 64, 8 classes, ResNet18 surrogate / clean model,
+    GridGenerator warp at 64 x 64)."""
+    cwd = str(tmp_path)
+    common = ["--dataset", "celeba", "--n_iters", "1"]
+    run("train_clean_classifier.py", "--saving_prefix", "classifier_clean", *common, cwd=cwd)
+    out = run("train_generator_wanet.py", "--saving_prefix", "train_generator_wanet", "--load_checkpoint_clean", "classifier_clean",
+              *common, cwd=cwd)
+    assert "Clean Acc:" in out and "Saving..." in out
+    gen = os.path.join(cwd, "ckpt", "train_generator_wanet_clean", "celeba", "celeba_train_generator_wanet_clean.pth.tar")
+    sd = torch.load(gen, map_location="cpu", weights_only=True)
+    assert sd["netC"]["linear.weight"].shape == (8, 2048) and len(sd["netG"]) == 20
+    assert all(torch.isfinite(v.float()).all() for v in sd["netC"].values())
+    assert all(torch.isfinite(v).all() for v in sd["netG"].values())
+
+
 def test_wanet_imagenet10_workflow_on_synthetic_data(tmp_path):
     """BASELINE config 5: --dataset imagenet10 (224 x 224, 10 classes, ResNet18(input_size=224), bs forced to 32 as
     reference train_generator_wanet.py:471-476).  The reference itself raises KeyError here."""

@@ -502,3 +502,35 @@ def test_wanet_alternated_step_trace(golden):
         for k in ("clean_correct", "bd_correct", "f_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr"):
             assert r[k] == int(g["trace/" + k][s]), (s, k)
     check_summary(g, "final/netg", og.items(), 1e-4)
+
+
+def test_wanet_trajectory_first_steps(golden):
+    """The first six steps of the 60-step WaNet trace (reference modules + torch.optim.SGD, lr 2e-3, B = 32) through the
+    oracle: losses to 2e-4, counters exact, the generator's field to 1e-5."""
+    from combat_amd import nets
+    from oracle import combat_oracle as O
+    g = golden("wanet_trajectory")
+
+    class WOpt:
+        s = 2
+
+    seeds = [int(v) for v in g["seeds"]]
+    mods = [seeded(nets.PreActResNet18, seeds[0]), seeded(nets.PreActResNet18, seeds[1]),
+            seeded(lambda: nets.GridGenerator(WOpt()), seeds[2]), seeded(lambda: nets.FrequencyModel(2, 3, 32), seeds[3])]
+    oc, ok, og, of = (state(m) for m in mods)
+    bufs_c, bufs_g = [None] * len(O.trainable_names(oc)), [None] * len(O.trainable_names(og))
+    lr = float(g["lr"])
+    cfg = O.StepConfig(trigger="wanet", lr_c=lr, lr_g=lr)
+    s_img, s_lab = (int(v) for v in g["pool_seeds"])
+    for s in range(6):
+        i = s % int(g["pool"])
+        x = synth_images(32, 32, s_img + i)
+        t = torch.randint(0, 10, (32,), generator=torch.Generator().manual_seed(s_lab + i))
+        field = O.grid_generator_forward(og, x[:1]).flatten()
+        np.testing.assert_allclose(field.numpy(), g["trace/field"][s], atol=1e-5)
+        r = O.alternated_step(oc, og, ok, of, bufs_c, bufs_g, x, t, O.StepRandomness(int(g["num_bd"][s]), 0.0, 0.0), cfg)
+        for k in ("loss_c", "loss_ce", "loss_l2", "loss_grad_l2", "clean_model_loss"):
+            ref = float(g["trace/" + k][s])
+            assert abs(r[k] - ref) < 2e-4 * max(1.0, abs(ref)) + 1e-7, (s, k, r[k], ref)
+        for k in ("clean_correct", "bd_correct", "f_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr"):
+            assert r[k] == int(g["trace/" + k][s]), (s, k)

@@ -303,3 +303,53 @@ def test_wanet_step_imagenet10_shape():
     fld = O.grid_generator_forward({k: v.cpu() for k, v in netg.state_dict().items()}, x[:1]).expand(4, -1, -1, -1)
     refw, _ = O.wanet_warp(x, fld, opt.grid_rescale)
     assert float((ours.cpu() - refw).abs().max()) < 2e-5 * 224 / 32
+
+
+def test_wanet_trajectory_vs_reference_trace(golden):
+    """60 WaNet steps (B = 32, lr 2e-3, recorded num_bd, no augmentation) against the trace of the reference modules +
+    torch.optim.SGD (tests/golden/make_golden.py::golden_wanet_trajectory).  EMA(0.1) of loss_c / clean_model_loss within
+    2 %, of loss_ce within 2 % + 0.02 (it falls from 2.3 to 0.02 over the run); the warp-field terms (fp32 functions of
+    the generator head, whose gradient passes through two bf16 classifiers) within 5 %; the field itself within 0.01 of
+    the reference's at every step (its components move by ~0.3 over the run); counters as in the UNet trajectory test."""
+    from combat_amd import nets, step as step_mod
+    from test_engine_gpu import _ema
+    g = golden("wanet_trajectory")
+    seeds = [int(v) for v in g["seeds"]]
+    netc, clean, netg, netf = _wanet_nets(nets, seeds)
+    opt = WOpt()
+    lr = float(g["lr"])
+    st = step_mod.WanetStep(netc.cuda(), netg.cuda(), clean.cuda().eval(), netf.cuda().eval(), opt)
+    s_img, s_lab = (int(v) for v in g["pool_seeds"])
+    pool, steps, b = int(g["pool"]), len(g["num_bd"]), 32
+    keys = ("loss_c_sum", "loss_ce_sum", "clean_model_loss_sum", "loss_l2_sum", "loss_grad_l2_sum", "clean_correct", "bd_correct",
+            "f_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr")
+    ours = {k: [] for k in keys}
+    fields = []
+    eng = netg._net_engine()
+    for s in range(steps):
+        i = s % pool
+        x = synth_images(b, 32, s_img + i)
+        t = torch.randint(0, 10, (b,), generator=torch.Generator().manual_seed(s_lab + i))
+        st.run(x.cuda(), t, step_mod.StepRandomness(int(g["num_bd"][s]), 0.5, 0.5, [None] * 5), lr_c=lr, lr_g=lr)
+        fields.append(eng.field.detach().cpu().numpy().copy())     # the field the step just used (before its update)
+        m = st.read_metrics(reset=True)
+        for k in keys:
+            ours[k].append(m[k])
+    report = {}
+    for ok_, rk, rel, floor in (("loss_c_sum", "loss_c", 0.02, 0.0), ("clean_model_loss_sum", "clean_model_loss", 0.02, 0.0),
+                                ("loss_ce_sum", "loss_ce", 0.02, 0.02), ("loss_l2_sum", "loss_l2", 0.05, 0.0),
+                                ("loss_grad_l2_sum", "loss_grad_l2", 0.05, 0.0)):
+        e_o, e_r = _ema(ours[ok_]), _ema(g["trace/" + rk])
+        dev = np.abs(e_o - e_r) - floor
+        report[rk] = float((dev / np.maximum(np.abs(e_r), 1e-9)).max())
+        assert np.all(dev <= rel * np.abs(e_r)), (rk, report[rk], int(np.argmax(dev / np.maximum(np.abs(e_r), 1e-9))))
+    fd = np.abs(np.array(fields) - g["trace/field"]).max()
+    assert fd < 1e-2, fd
+    print("wanet trajectory: max relative EMA deviations", report, "max field deviation", fd)
+    for k in ("clean_correct", "bd_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr", "f_correct"):
+        d = np.abs(np.array(ours[k], dtype=np.float64) - g["trace/" + k])
+        assert np.all(d <= 10) and (d <= 4).mean() >= 0.95, (k, np.nonzero(d > 4)[0].tolist(), d.max())
+    for k in ("fc1.bias", "fc2.weight", "fc2.bias"):
+        ref = g["final/" + k]
+        got = dict(netg.named_parameters())[k].detach().cpu().numpy()
+        assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max()), (k, np.abs(got - ref).max())
