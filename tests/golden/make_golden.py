@@ -220,18 +220,19 @@ def _low_freq(x, ratio=0.65):
     return ref_dct.idct_2d(d) / 255 * 2 - 1
 
 
-def _alternated_trace(out, b, steps, batches, num_bds, sig_c, sig_g, record_inputs, final=True, lr=1e-2):
+def _alternated_trace(out, b, steps, batches, num_bds, sig_c, sig_g, record_inputs, final=True, lr=1e-2, make_clf=None, hw=32):
     """`steps` alternated steps driven through the reference nn.Modules + torch.optim.SGD in the order of
     train_generator.py:170-255 (no augmentation = --post_transform_option no_use, recorded num_bd / sigma;
     Gaussian blur restated: torchvision is absent).  batches(s) -> (inputs, targets) of step s."""
+    make_clf = make_clf or PreActResNet18
     torch.manual_seed(0)
-    netc = PreActResNet18()
+    netc = make_clf()
     torch.manual_seed(1)
-    clean = PreActResNet18().eval()
+    clean = make_clf().eval()
     torch.manual_seed(2)
     netg = UnetGenerator(Opt())
     torch.manual_seed(3)
-    netf = FrequencyModel(num_classes=2, n_input=3, input_size=32).eval()
+    netf = FrequencyModel(num_classes=2, n_input=3, input_size=hw).eval()
     out["seeds"] = np.array([0, 1, 2, 3])
     opt_c = torch.optim.SGD(netc.parameters(), lr, momentum=0.9, weight_decay=5e-4, nesterov=True)
     opt_g = torch.optim.SGD(netg.parameters(), lr, momentum=0.9, weight_decay=5e-4, nesterov=True)
@@ -364,6 +365,22 @@ def golden_trajectory(lr=1e-2, name="trajectory.npz"):
     _alternated_trace(out, b, steps, lambda s: pool[s % POOL], num_bds, sig_c, sig_g, False, final=True, lr=lr)
     out["pool_seeds"], out["pool"] = np.array([7000, 7100]), np.int64(POOL)
     save(name, out)
+
+
+def golden_trajectory_celeba():
+    """BASELINE config 4's shape: 40 alternated steps at B = 16 of 3 x 64 x 64 images, 8 classes, ResNet18 surrogate and
+    clean model (train_generator.py:93-96), UNet at 64 x 64, lr 2e-3, pool of 10 batches, no augmentation."""
+    out = {}
+    steps, b, POOL = 40, 16, 10
+    pool = [(synth_images(b, 64, 7300 + i), torch.randint(0, 8, (b,), generator=rng(7400 + i))) for i in range(POOL)]
+    g = np.random.default_rng(98)
+    num_bds = [int((g.random(int((pool[s % POOL][1] == 0).sum())) < 0.5).sum()) for s in range(steps)]
+    sig_c = g.uniform(0.1, 1.0, steps).round(4).tolist()
+    sig_g = g.uniform(0.1, 1.0, steps).round(4).tolist()
+    _alternated_trace(out, b, steps, lambda s: pool[s % POOL], num_bds, sig_c, sig_g, False, final=True, lr=2e-3,
+                      make_clf=lambda: ResNet18(num_classes=8, input_size=64), hw=64)
+    out["pool_seeds"], out["pool"] = np.array([7300, 7400]), np.int64(POOL)
+    save("trajectory_celeba.npz", out)
 
 
 def golden_trajectory_lr2e3():

@@ -556,7 +556,7 @@ def _ema(v, a=0.1):
     return np.array(out)
 
 
-@pytest.mark.parametrize("name,steps", [("trajectory_lr2e3", 100), ("trajectory", 40)])
+@pytest.mark.parametrize("name,steps", [("trajectory_lr2e3", 100), ("trajectory", 40), ("trajectory_celeba", 40)])
 def test_trajectory_vs_reference_trace(mods, golden, name, steps):
     """SURVEY 8(d) / north_star "loss curves must match": alternated steps at B = 32 over a pool of 25 fixed
     synthetic batches (augmentation off, recorded num_bd / sigma per step) against the trace the REFERENCE's
@@ -571,19 +571,31 @@ def test_trajectory_vs_reference_trace(mods, golden, name, steps):
     EMA at step 99 = 0.05 absolute.)
     `trajectory` (the default lr 1e-2): the reference's own run turns chaotic after ~45 steps on these
     random-label batches (loss_ce jumps between 0 and 50-290), so only its smooth first 40 steps are compared:
-    loss_c / clean_model_loss / loss_l2 EMAs within 5 %, loss_ce within 5 % + 0.03."""
-    step_mod = mods["step"]
+    loss_c / clean_model_loss / loss_l2 EMAs within 5 %, loss_ce within 5 % + 0.03.
+    `trajectory_celeba` (BASELINE config 4's shape: 3 x 64 x 64, 8 classes, ResNet18 surrogate and clean model, B = 16,
+    lr 2e-3, 40 steps -- the surrogate memorises the 160 images, loss_c 2.08 -> 0.03, and the trigger wins within 20 steps,
+    loss_ce -> 1e-5): loss_c / clean_model_loss / loss_l2 EMAs within 5 %, loss_ce within 5 % + 0.03."""
+    step_mod, nets = mods["step"], mods["nets"]
     g = golden(name)
     seeds = [int(s) for s in g["seeds"]]
-    netc, clean, netg, netf = _build(mods, seeds)
+    celeba = name == "trajectory_celeba"
     opt = Opt()
+    if celeba:
+        mk = lambda: nets.ResNet18(num_classes=8, input_size=64)
+        netc, clean = seeded(mk, seeds[0]), seeded(mk, seeds[1])
+        netg = seeded(lambda: nets.UnetGenerator(None), seeds[2])
+        netf = seeded(lambda: nets.FrequencyModel(2, 3, 64), seeds[3]).eval()
+        opt.num_classes, opt.input_height, opt.input_width, opt.dataset = 8, 64, 64, "celeba"
+    else:
+        netc, clean, netg, netf = _build(mods, seeds)
     st = step_mod.AlternatedStep(netc.cuda(), netg.cuda(), clean.cuda().eval(), netf.cuda().eval(), opt)
-    b, pool_n, lr = 32, int(g["pool"]), float(g["lr"])
+    b, pool_n, lr = (16 if celeba else 32), int(g["pool"]), float(g["lr"])
+    hw, ncls = opt.input_height, opt.num_classes
     s_img, s_lab = (int(v) for v in g["pool_seeds"])
 
     def synth(i):
-        u8 = torch.randint(0, 256, (b, 3, 32, 32), generator=torch.Generator().manual_seed(s_img + i), dtype=torch.uint8)
-        return (u8.float() / 255 - 0.5) / 0.5, torch.randint(0, 10, (b,), generator=torch.Generator().manual_seed(s_lab + i))
+        u8 = torch.randint(0, 256, (b, 3, hw, hw), generator=torch.Generator().manual_seed(s_img + i), dtype=torch.uint8)
+        return (u8.float() / 255 - 0.5) / 0.5, torch.randint(0, ncls, (b,), generator=torch.Generator().manual_seed(s_lab + i))
 
     pool = [synth(i) for i in range(pool_n)]
     keys = (("loss_c_sum", "loss_c"), ("loss_ce_sum", "loss_ce"), ("clean_model_loss_sum", "clean_model_loss"),
@@ -622,9 +634,10 @@ def test_trajectory_vs_reference_trace(mods, golden, name, steps):
         # gradients), so a single step of a crossing can be 5-8 images off in one run and exact in the next.
         # (past step 60 bd_correct follows the spiky loss_ce, see above)
         d = np.abs(o - r)
-        assert np.all(d <= 10), (name, k, int(d.argmax()), d.max())
+        near, far = max(2, b // 8), max(4, 10 * b // 32)       # 4 and 10 images at B = 32
+        assert np.all(d <= far), (name, k, int(d.argmax()), d.max())
         head = d[: min(60, steps)]
-        assert (head <= 4).mean() >= 0.95, (name, k, np.nonzero(head > 4)[0].tolist(), head.max())
+        assert (head <= near).mean() >= 0.95, (name, k, np.nonzero(head > near)[0].tolist(), head.max())
         assert abs(o.sum() - r.sum()) <= max(0.015 * steps * b, 8), (name, k, o.sum(), r.sum())
 
 
