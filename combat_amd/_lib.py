@@ -116,6 +116,7 @@ SIGNATURES = {
     "combat_memset_zero": (C.c_int, [c_vp, c_i64, c_vp]),
     "combat_relu_mask": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "combat_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "combat_log_terms": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "combat_maxpool2": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_elu_affine": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "combat_affine_act": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_f32, c_vp, c_vp]),

@@ -409,6 +409,80 @@ inline unsigned grid_for(long total, int cap = 4096) {
     return (unsigned)b;
 }
 
+
+// ------------------------------------------------------------------ logged-only terms of the alternated step
+// One launch for what the reference computes with a dozen ATen calls per step (train_generator.py:234-247):
+//   acc[0] += sum(mse_partial) / (n 3 H W)                                   loss_l2 (from the trigger kernel's partials)
+//   acc[1] += mean(dH(pad(x)) - dH(pad(xb)))^2 + mean(dW(pad(x)) - dW(pad(xb)))^2   loss_grad_l2, pad = F.pad(., (1, 1, 2, 1)):
+//             one zero column left and right, two zero rows above, one below; both differences are linear, so they are
+//             taken of delta = x - xb
+//   hits   += #{images : logits[i][1] > logits[i][0]}                           detector says "backdoor" (argmax == 1)
+// Workgroup = one (image, channel) plane; fp64 accumulators, one atomic per workgroup and term.
+__global__ __launch_bounds__(256) void log_terms_kernel(const float *__restrict__ x, const float *__restrict__ xb,
+                                                        const float *__restrict__ mse_partial, int n_partial, int n, int hw,
+                                                        const float *__restrict__ logits, int n_logits,
+                                                        double *__restrict__ acc, double *__restrict__ hits) {
+    __shared__ float red[2][256];
+    const int tid = threadIdx.x, plane = blockIdx.x;
+    const float *px = x + (long)plane * hw * hw, *pb = xb + (long)plane * hw * hw;
+    auto delta = [&](int r, int c) -> float {       // padded coordinates: rows 0..hw+2, columns 0..hw+1
+        const int y = r - 2, xx = c - 1;
+        return ((unsigned)y < (unsigned)hw && (unsigned)xx < (unsigned)hw) ? px[y * hw + xx] - pb[y * hw + xx] : 0.f;
+    };
+    float sh = 0.f, sw = 0.f;
+    const int PH = hw + 3, PW = hw + 2;
+    for (int i = tid; i < (PH - 1) * PW; i += 256) {          // differences along H: (PH - 1) x PW values
+        const int r = i / PW, c = i - r * PW;
+        const float d = delta(r + 1, c) - delta(r, c);
+        sh = fmaf(d, d, sh);
+    }
+    for (int i = tid; i < PH * (PW - 1); i += 256) {          // along W: PH x (PW - 1)
+        const int r = i / (PW - 1), c = i - r * (PW - 1);
+        const float d = delta(r, c + 1) - delta(r, c);
+        sw = fmaf(d, d, sw);
+    }
+    red[0][tid] = sh;
+    red[1][tid] = sw;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[0][tid] += red[0][tid + s];
+            red[1][tid] += red[1][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double planes = (double)n * 3.0;
+        atomicAdd(acc + 1, (double)red[0][0] / (planes * (PH - 1) * PW) + (double)red[1][0] / (planes * PH * (PW - 1)));
+    }
+    if (plane == 0) {
+        if (mse_partial) {
+            double s = 0.0;
+            for (int i = tid; i < n_partial; i += 256) s += (double)mse_partial[i];
+            __shared__ double rd[256];
+            rd[tid] = s;
+            __syncthreads();
+            for (int k = 128; k > 0; k >>= 1) {
+                if (tid < k) rd[tid] += rd[tid + k];
+                __syncthreads();
+            }
+            if (tid == 0) atomicAdd(acc, rd[0] / ((double)n * 3.0 * hw * hw));
+        }
+        if (logits && hits) {
+            int h = 0;
+            for (int i = tid; i < n_logits; i += 256) h += logits[2 * i + 1] > logits[2 * i] ? 1 : 0;
+            __shared__ int rh[256];
+            rh[tid] = h;
+            __syncthreads();
+            for (int k = 128; k > 0; k >>= 1) {
+                if (tid < k) rh[tid] += rh[tid + k];
+                __syncthreads();
+            }
+            if (tid == 0) atomicAdd(hits, (double)rh[0]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int combat_pack_weights(const float *w, int32_t K, int32_t taps, int32_t c_real, int32_t C,
@@ -467,6 +541,15 @@ extern "C" int combat_memset_zero(void *ptr, int64_t bytes, void *stream) {
     if (!ptr || bytes < 0) return COMBAT_EINVAL;
     if (bytes == 0) return COMBAT_OK;
     return hipMemsetAsync(ptr, 0, (size_t)bytes, as_stream(stream)) == hipSuccess ? COMBAT_OK : COMBAT_ELAUNCH;
+}
+
+extern "C" int combat_log_terms(const float *x, const float *xb, const float *mse_partial, int32_t n, int32_t hw,
+                                const float *detector_logits, double *acc2, double *hits, void *stream) {
+    if (!x || !xb || !acc2 || n <= 0 || hw < 2) return COMBAT_EINVAL;
+    hipLaunchKernelGGL(log_terms_kernel, dim3(3 * n), dim3(256), 0, as_stream(stream), x, xb, mse_partial, 3 * n, n, hw,
+                       detector_logits, n, acc2, hits);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
 }
 
 extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream) {

@@ -379,8 +379,7 @@ class AlternatedStep:
             if eF is not None:
                 ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), s2), "dct")
                 pl["F_f"].run(prof)
-                self.acc_side += (self.sF.bufs["logits"].argmax(1) == 1).sum()
-            self._log_l2_terms(n)
+            self._log_terms(n, s2, self.sF.bufs["logits"] if eF is not None else None)
             ev_met = torch.cuda.Event()
             ev_met.record()
         torch.cuda.current_stream().wait_event(ev_side)     # ---- join
@@ -413,10 +412,12 @@ class AlternatedStep:
         ops.check(lib.combat_trigger_fwd(x_ptr, self.eG.output(self.sG).data_ptr(), self.P.data_ptr(), k1g, float(self.opt.noise_rate),
                                          n, self.hw, None, self.bd.data_ptr(), None, self.mse.data_ptr(), s2), "trigger G")
 
-    def _log_l2_terms(self, n) -> None:
-        """loss_l2 / loss_grad_l2 running sums (train_generator.py:234-243; the second is logged only)."""
-        self.acc[0] += self.mse.sum() / float(n * 3 * self.hw * self.hw)
-        self.acc[1] += self._grad_l2(self.inputs, self.bd)
+    def _log_terms(self, n, s2, f_logits) -> None:
+        """loss_l2 / loss_grad_l2 running sums (train_generator.py:234-243; the second is logged only) and the
+        detector's hit count (:245-247), in one launch (the ATen spelling of the same is _grad_l2 below: 14 launches)."""
+        ops.check(lib.combat_log_terms(self.inputs.data_ptr(), self.bd.data_ptr(), self.mse.data_ptr(), n, self.hw,
+                                       f_logits.data_ptr() if f_logits is not None else None, self.acc.data_ptr(),
+                                       self.acc_side.data_ptr(), s2), "log terms")
 
     def _gen_backward(self, x_ptr, n, k1g, st, prof) -> None:
         """Image gradient (d_bd + d_bd2) + the L2 term -> generator parameter gradients (train_generator.py:253-254)."""
@@ -544,7 +545,9 @@ class WanetStep(AlternatedStep):
     def _trigger_g(self, x_ptr, n, k1g, s2) -> None:
         ops.check(lib.combat_warp_fwd(x_ptr, None, self.g["grid"].data_ptr(), 0, n, self.hw, self.bd.data_ptr(), s2), "warp G")
 
-    def _log_l2_terms(self, n) -> None:
+    def _log_terms(self, n, s2, f_logits) -> None:
+        if f_logits is not None:
+            self.acc_side += (f_logits.argmax(1) == 1).sum()
         ng = self.g["noise_grid"]                      # [H][H][2]; the reference's noise_grid is B equal copies
         self.acc[0] += ng.pow(2).mean()
         F = torch.nn.functional

@@ -394,6 +394,12 @@ int combat_relu_mask(const void *g, const void *act, int64_t elements, void *out
 int combat_memset_zero(void *ptr, int64_t bytes, void *stream);
 /* column sums of a bf16 [rows][C] tensor into fp32 out[c_out] (overwritten): conv bias gradient */
 int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream);
+/* The logged-only terms of one step in one launch (train_generator.py:234-247): acc2[0] += MSE(inputs_bd, inputs) from the
+ * trigger kernel's per-plane partial sums (mse_partial [3n], may be NULL), acc2[1] += loss_grad_l2 = MSE of the H- and
+ * W-differences of F.pad(x, (1, 1, 2, 1)) and F.pad(xb, ...), hits += #{i : argmax(detector_logits[i]) == 1} ([n][2], may be
+ * NULL).  x, xb: fp32 [n][3][hw][hw]; acc2, hits: fp64 device accumulators. */
+int combat_log_terms(const float *x, const float *xb, const float *mse_partial, int32_t n, int32_t hw,
+                     const float *detector_logits, double *acc2, double *hits, void *stream);
 /* 2x2 max pool, bf16 NHWC (frequency model.py:21,32,43) */
 int combat_maxpool2(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, void *out, void *stream);
 /* y = BN_eval(ELU(x)) elementwise per channel, bf16 in/out (frequency model.py:14-16) */

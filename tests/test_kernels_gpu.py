@@ -1157,3 +1157,27 @@ def test_invalid_arguments_are_rejected(ops):
         ops.conv_launch(a)
     with pytest.raises(CombatHipError):
         ops.maxpool2(torch.zeros(1, 3, 3, 8, dtype=bf16, device="cuda"), y)
+
+
+@pytest.mark.parametrize("n,hw", [(5, 32), (3, 64)])
+def test_log_terms_equal_the_aten_spelling(n, hw):
+    """combat_log_terms against the reference's own expressions (train_generator.py:234-247): MSE from per-plane partial
+    sums, loss_grad_l2 through F.pad(., (1, 1, 2, 1)) and the two difference tensors, argmax == 1 count."""
+    import torch.nn.functional as F
+    from combat_amd import ops as O_
+    from combat_amd._lib import lib
+    from combat_amd.step import AlternatedStep
+    x = torch.rand(n, 3, hw, hw, generator=g(300)).cuda() * 2 - 1
+    xb = (x + 0.05 * torch.randn(n, 3, hw, hw, generator=g(301)).cuda()).clamp(-1, 1)
+    mse = ((xb - x) ** 2).sum((2, 3)).reshape(-1).contiguous()
+    logits = torch.randn(n, 2, generator=g(302)).cuda()
+    logits[0, 1] = logits[0, 0]          # a tie is class 0 (argmax returns the first maximum)
+    acc = torch.tensor([1.5, 2.5, 0, 0, 0, 0, 0, 0], dtype=torch.float64, device="cuda")
+    hits = torch.tensor(3.0, dtype=torch.float64, device="cuda")
+    O_.check(lib.combat_log_terms(x.data_ptr(), xb.data_ptr(), mse.data_ptr(), n, hw, logits.data_ptr(), acc.data_ptr(),
+                                  hits.data_ptr(), torch.cuda.current_stream().cuda_stream), "log terms")
+    torch.cuda.synchronize()
+    assert abs(float(acc[0]) - 1.5 - float(F.mse_loss(xb, x))) < 1e-6 * float(F.mse_loss(xb, x)) + 1e-9
+    ref = float(AlternatedStep._grad_l2(x, xb))
+    assert abs(float(acc[1]) - 2.5 - ref) < 1e-5 * ref + 1e-9, (float(acc[1]) - 2.5, ref)
+    assert float(hits) == 3.0 + float((logits.argmax(1) == 1).sum())
