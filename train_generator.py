@@ -104,20 +104,27 @@ def eval(netC, optimizerC, schedulerC, netG, optimizerG, schedulerG, netF, clean
             inputs, targets = inputs.to(opt.device), targets.to(opt.device)
             preds_clean = netC(inputs)
             c["clean_n"] += len(inputs)
-            c["clean"] += int((preds_clean.argmax(1) == targets).sum())
             ntrg = (targets != opt.target_label).nonzero()[:, 0]
             inputs_toChange, targets_toChange = inputs[ntrg], targets[ntrg]
             inputs_bd = api.create_backdoor(netG, inputs_toChange, opt)     # random sigma at eval too (:353,:373)
             targets_bd = create_targets_bd(targets_toChange, opt).to(opt.device)
             c["bd_n"] += len(ntrg)
+            # the six counters of this batch in ONE device->host read (the reference reads each one separately)
+            cnt = [(preds_clean.argmax(1) == targets).sum(), (clean_model(inputs).argmax(1) == targets).sum()]
             if len(ntrg):
                 preds_bd = netC(inputs_bd)
-                c["bd"] += int((preds_bd.argmax(1) == targets_bd).sum())
-                c["F"] += int((api.frequency_logits(netF, inputs_bd, opt).argmax(1) == 1).sum())
-                cm_bd = clean_model(inputs_bd)
-                c["cm_ba"] += int((cm_bd.argmax(1) == targets_toChange).sum())
-                c["cm_asr"] += int((cm_bd.argmax(1) == targets_bd).sum())
-            c["cm"] += int((clean_model(inputs).argmax(1) == targets).sum())
+                cm_bd = clean_model(inputs_bd).argmax(1)
+                cnt += [(preds_bd.argmax(1) == targets_bd).sum(),
+                        (api.frequency_logits(netF, inputs_bd, opt).argmax(1) == 1).sum(),
+                        (cm_bd == targets_toChange).sum(), (cm_bd == targets_bd).sum()]
+            cnt = torch.stack(cnt).cpu().tolist()
+            c["clean"] += int(cnt[0])
+            c["cm"] += int(cnt[1])
+            if len(ntrg):
+                c["bd"] += int(cnt[2])
+                c["F"] += int(cnt[3])
+                c["cm_ba"] += int(cnt[4])
+                c["cm_asr"] += int(cnt[5])
         acc_clean = c["clean"] * 100.0 / c["clean_n"]
         bd_n = max(c["bd_n"], 1)
         acc_bd, acc_F = c["bd"] * 100.0 / bd_n, c["F"] * 100.0 / bd_n
