@@ -71,6 +71,7 @@ SIGNATURES = {
     "combat_version": (C.c_char_p, []),
     "combat_abi_version": (C.c_int, []),
     "combat_conv_gemm": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
+    "combat_conv_gemm_pair": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), c_vp]),
     "combat_conv_workspace_bytes": (c_i64, [C.POINTER(ConvArgs)]),
     "combat_conv_pick_tile": (C.c_int, [C.POINTER(ConvArgs)]),
     "combat_conv_stats_granule": (C.c_int, [C.c_int]),

@@ -17,6 +17,7 @@ bool conv_gather_dma_parity_split(const combat_conv_args *a);      // statistics
 bool conv_c8_ok(const combat_conv_args *a);
 int conv_c8_launch(const combat_conv_args *a, hipStream_t st);
 int conv_gather_dma_launch(const combat_conv_args *a, hipStream_t st);
+int conv_gather_dma_pair_launch(const combat_conv_args *a, const combat_conv_args *b, hipStream_t st);   // 1: not groupable
 long conv_gather_dma_workspace(const combat_conv_args *a);        // scratch bytes a split reduction would use
 // halo weight-gradient kernel (conv_wgrad3x3.hip): 0 launched, 1 not applicable, <0 error
 int conv_wgrad3x3_try(const combat_wgrad_args *a, hipStream_t st);

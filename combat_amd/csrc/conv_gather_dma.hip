@@ -35,6 +35,7 @@ struct GatherParams {
     int splits;                  // > 1: the reduction steps of a tile are divided among `splits` workgroups that
     float *ws;                   //      write fp32 slabs [split][tile][128][BN] here; conv_gather_finish_kernel combines
     int flavour;                 // epilogue specialisation (conv_dma_epilogue.hpp), -1: generic
+    int block_base;              // first workgroup of this problem in the launch (0 unless it is the second of a pair)
     int w_prefetch;              // warm the XCD's L2 with this workgroup's weight rows at kernel start (conv3x3_dma.hip)
     unsigned long long *stamps;  // profiling builds only (-DCOMBAT_STAMPS): per workgroup, cycles per phase
 };
@@ -74,8 +75,9 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     int pf_rank = 0, pf_size = 1;   // this workgroup's place among the workgroups of its XCD that share its weight rows
     {
         const int ntile = p.tiles_m * p.tiles_n;
-        const int nb = ntile, bid = blockIdx.x % ntile;
-        sp = blockIdx.x / ntile;                       // slab of a split reduction (0 otherwise)
+        const int wg_index = blockIdx.x - (unsigned)p.block_base;   // (no cast of blockIdx.x itself: the host pass cannot convert it)
+        const int nb = ntile, bid = wg_index % ntile;
+        sp = wg_index / ntile;                           // slab of a split reduction (0 otherwise)
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
         const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
         tile = base + idx;
@@ -460,9 +462,22 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
 #endif
 }
 
+__device__ __forceinline__ const GatherParams &pick(const GatherParams &a, const GatherParams &b, int n0) {
+    return blockIdx.x >= (unsigned)n0 ? b : a;
+}
+
+struct GatherPair {
+    GatherParams p[2];
+    int n0;
+};
+
+// Workgroups [0, n0) run problem 0, the rest problem 1 (n0 = the whole grid for an ordinary launch).  Two independent
+// convolutions in ONE launch: a residual block's stride-2 first convolution and its 1x1 shortcut (preact_resnet.py:33-36,
+// resnet.py:24-31: both read the same activated tensor) -- the shortcut's 0.6 GFLOP ride along in slots the 3x3 launch
+// leaves idle instead of paying a dependent 12-17 us launch of their own.
 template <int BN, int NS>
-__global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_kernel(const GatherParams p) {
-    conv_gather_dma_body<BN, false, NS>(p);
+__global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_kernel(const GatherPair pp) {
+    conv_gather_dma_body<BN, false, NS>(pick(pp.p[0], pp.p[1], pp.n0));
 }
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv_gather_finish_kernel(const GatherParams p) { conv_gather_dma_body<BN, true, 3>(p); }
@@ -574,8 +589,7 @@ bool psplit_ok(const combat_conv_args &a) {
 }
 
 template <int BN>
-int launch(const combat_conv_args *a, hipStream_t st) {
-    GatherParams p;
+void fill(const combat_conv_args *a, GatherParams &p) {
     p.a = *a;
     p.PQ = a->P * a->Q;
     p.M = a->N * p.PQ;
@@ -601,12 +615,20 @@ int launch(const combat_conv_args *a, hipStream_t st) {
     if (p.splits > 1 && (!a->workspace || a->workspace_bytes < need)) p.splits = 1;
     p.ws = p.splits > 1 ? reinterpret_cast<float *>(a->workspace) : nullptr;
     p.flavour = epi_flavour_of(*a);
+    p.block_base = 0;
     p.w_prefetch = (long)a->C * p.ntaps >= 1024 && !getenv("COMBAT_NO_WPREFETCH");   // >= 16 lines per weight row
 #ifdef COMBAT_STAMPS
     p.stamps = g_stamps_gather_host;
 #else
     p.stamps = nullptr;
 #endif
+}
+
+template <int BN>
+int launch(const combat_conv_args *a, hipStream_t st) {
+    static GatherPair pp;    // (filled per call, passed by value)
+    GatherParams &p = pp.p[0];
+    fill<BN>(a, p);
     constexpr int stage = 128 * 128 + BN * 128;
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
     constexpr int smem = (3 * stage > ep ? 3 * stage : ep) + 1024;   // (+ the weight prefetch's scratch KB)
@@ -623,7 +645,8 @@ int launch(const combat_conv_args *a, hipStream_t st) {
         attr_set = true;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(tiles * (p.splits > 1 ? p.splits : 1)), dim3(256), smem, st, p);
+    pp.n0 = tiles * (p.splits > 1 ? p.splits : 1);
+    hipLaunchKernelGGL(kern, dim3(pp.n0), dim3(256), smem, st, pp);
     CB_LAUNCH_CHECK();
     if (p.splits > 1) {
         hipLaunchKernelGGL(fin, dim3(tiles), dim3(256), ep, st, p);
@@ -711,6 +734,42 @@ long conv_gather_dma_workspace(const combat_conv_args *a) {
 
 bool conv_gather_dma_parity_split(const combat_conv_args *a) {
     return psplit_ok(*a) && ((long)a->N * a->P * a->Q / 4) % 128 == 0;
+}
+
+namespace {
+template <int BN>
+int launch_pair(const combat_conv_args *a, const combat_conv_args *b, hipStream_t st) {
+    static GatherPair pp;      // (2 x ~400 B of kernel arguments; filled per call, passed by value)
+    fill<BN>(a, pp.p[0]);
+    fill<BN>(b, pp.p[1]);
+    if (pp.p[0].splits > 1 || pp.p[1].splits > 1) return 1;   // split reductions have a finish launch each: not grouped
+    constexpr int stage = 128 * 128 + BN * 128;
+    constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
+    constexpr int smem = (3 * stage > ep ? 3 * stage : ep) + 1024;
+    auto kern = conv_gather_dma_kernel<BN, 3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_set = true;
+    }
+    // (tried: the two problems' workgroups alternating in groups of eight, so that the short one runs beside the long
+    // one from the start instead of as a tail -- same launch time, same step)
+    const int n0 = pp.p[0].tiles_m * pp.p[0].tiles_n, n1 = pp.p[1].tiles_m * pp.p[1].tiles_n;
+    pp.n0 = n0;
+    pp.p[1].block_base = n0;
+    hipLaunchKernelGGL(kern, dim3(n0 + n1), dim3(256), smem, st, pp);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+}  // namespace
+
+// both convolutions in one launch: COMBAT_OK; 1: not groupable (the caller launches them one after the other)
+int conv_gather_dma_pair_launch(const combat_conv_args *a, const combat_conv_args *b, hipStream_t st) {
+    const int bn = conv_gather_dma_bn(a);
+    if (!bn || bn != conv_gather_dma_bn(b)) return 1;
+    if (a->tile || b->tile) return 1;
+    return bn == 64 ? launch_pair<64>(a, b, st) : launch_pair<32>(a, b, st);
 }
 
 int conv_gather_dma_launch(const combat_conv_args *a, hipStream_t st) {

@@ -383,6 +383,24 @@ extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows
     return COMBAT_OK;
 }
 
+extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream);
+
+// Two convolutions with no data dependence between them (neither reads what the other writes): one launch when both take
+// the gather kernel with the same channel tile and unsplit reductions, otherwise a, then b.
+extern "C" int combat_conv_gemm_pair(const combat_conv_args *a, const combat_conv_args *b, void *stream) {
+    if (!a || !b) return COMBAT_EINVAL;
+    const int ta = pick_tile(a), tb = pick_tile(b);
+    const bool gather = (ta == COMBAT_TILE_G128x64 || ta == COMBAT_TILE_G128x32) && ta == tb;
+    if (gather && a->src && b->src && a->wpack && b->wpack && (a->dst || a->act_dst) && (b->dst || b->act_dst) &&
+        a->stats_kind >= 0 && a->stats_kind <= 2 && b->stats_kind >= 0 && b->stats_kind <= 2 && (!a->stats_kind || a->stats) &&
+        (!b->stats_kind || b->stats)) {
+        const int rc = conv_gather_dma_pair_launch(a, b, as_stream(stream));
+        if (rc != 1) return rc;
+    }
+    const int rc = combat_conv_gemm(a, stream);
+    return rc ? rc : combat_conv_gemm(b, stream);
+}
+
 extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     if (!a || !a->src || !a->wpack || (!a->dst && !a->act_dst)) return COMBAT_EINVAL;
     if (a->act_dst && (!a->act_scale || !a->act_shift)) return COMBAT_EINVAL;

@@ -62,6 +62,14 @@ class Plan:
     def hold(self, *objs) -> None:
         self._keep.extend(objs)
 
+    def merge_convs(self, i: int) -> None:
+        """Calls i and i + 1 are two combat_conv_gemm launches with no data dependence between them (a residual
+        block's shortcut and its first convolution over the same input): make them ONE combat_conv_gemm_pair call.
+        Only while nothing recorded after them is indexed by position (forward plans: no marks, no aux calls)."""
+        (f0, a0, w0), (f1, a1, w1) = self.calls[i], self.calls[i + 1]
+        assert f0 is lib.combat_conv_gemm and f1 is lib.combat_conv_gemm and not self.marks and not self.aux
+        self.calls[i:i + 2] = [(lib.combat_conv_gemm_pair, (a0[0], a1[0]), w0 + "+" + w1)]
+
     def workspace(self, device) -> torch.Tensor:
         """Scratch of this plan's convolutions (split reductions of skinny layers).  Per plan: the calls of
         one plan run one after the other on one stream, two plans may run concurrently."""
@@ -86,7 +94,15 @@ class Plan:
             auxs = [_aux_stream(stream, k) for k in range(self.aux_queues)]
         used = set()
         for ci, (cfunc, args, what) in enumerate(self.calls):
-            if prof is not None and (cfunc is lib.combat_conv_gemm or cfunc is lib.combat_conv_wgrad):
+            if prof is not None and cfunc is lib.combat_conv_gemm_pair:     # measured one kernel at a time
+                rc = 0
+                for sub, arg in zip(what.split("+"), args):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    rc = rc or lib.combat_conv_gemm(arg, st)
+                    e1.record(stream)
+                    prof.append((self.name + "/" + sub, arg._obj, e0, e1))
+            elif prof is not None and (cfunc is lib.combat_conv_gemm or cfunc is lib.combat_conv_wgrad):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 rc = cfunc(*args, st)
@@ -669,6 +685,7 @@ class PreActEngine(NetEngine):
         chw = hw
         for b, blk in enumerate(self.blocks):
             ohw = chw // blk.stride
+            i_sc = len(P.calls)
             if blk.sc is not None:
                 resid = slot.buf("b%d.sc" % b, (n, ohw, ohw, blk.planes))
                 rec_conv(P, "b%d.sc" % b, a0, resid, blk.sc, 0)
@@ -680,6 +697,8 @@ class PreActEngine(NetEngine):
             a1 = slot.buf("b%d.a1t" % b, y1.shape)
             self._conv_norm(P, slot, blk.bn2.prefix, a0, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
                             beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt), act_dst=a1)
+            if blk.sc is not None:      # shortcut + first convolution: one launch (both read a0)
+                P.merge_convs(i_sc)
             if nxt is not None:
                 a0 = slot.buf("b%d.a0" % (b + 1), out.shape)
                 self._conv_norm(P, slot, nxt.prefix, a1, out, blk.conv2, groups=1, gamma=nxt.gamma, beta=nxt.beta,
@@ -712,6 +731,8 @@ class PreActEngine(NetEngine):
                 resid = raw
             a1 = slot.buf("b%d.a1" % b, shape)
             rec_conv(P, "b%d.c1" % b, act, None, blk.conv1, 0, act_dst=a1, act=blk.bn2.eval_affine())
+            if blk.sc is not None:
+                P.merge_convs(len(P.calls) - 2)
             nxt = blocks[b + 1] if b + 1 < len(blocks) else None
             keep_raw = nxt is None or nxt.sc is None
             out = slot.buf("b%d.out" % b, shape) if keep_raw else None
@@ -890,6 +911,7 @@ class ResNetEngine(PreActEngine):
             if blk.sc is not None:
                 resid = slot.buf("b%d.scv" % b, shape)
                 rec_conv(P, "b%d.sc" % b, cur, resid, blk.sce, 0, bias=blk.bns.eshift)
+                P.merge_convs(len(P.calls) - 2)
             else:
                 resid = cur
             out = slot.buf("b%d.out" % b, shape)

@@ -132,6 +132,10 @@ typedef struct combat_conv_args {
 #define COMBAT_TILE_D256W64 16   /* conv3x3_dma, 256-pixel tiles as four waves of 64 pixels x 64 channels (16-wide maps, >= 16 rows) */
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);
+/* Two convolutions that do not depend on each other, in stream order a then b -- as ONE launch where both take the
+ * gathered-DMA kernel with the same channel tile (a residual block's stride-2 first convolution and its 1x1 shortcut over
+ * the same activated input: preact_resnet.py:33-36, resnet.py:24-31).  Results equal two combat_conv_gemm calls. */
+int combat_conv_gemm_pair(const combat_conv_args *a, const combat_conv_args *b, void *stream);
 /* scratch bytes the launch for these args can use (0: none) */
 int64_t combat_conv_workspace_bytes(const combat_conv_args *a);
 /* tile the launcher would pick for these args (a->tile honoured) and its stats granule */

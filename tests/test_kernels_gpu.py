@@ -1181,3 +1181,58 @@ def test_log_terms_equal_the_aten_spelling(n, hw):
     ref = float(AlternatedStep._grad_l2(x, xb))
     assert abs(float(acc[1]) - 2.5 - ref) < 1e-5 * ref + 1e-9, (float(acc[1]) - 2.5, ref)
     assert float(hits) == 3.0 + float((logits.argmax(1) == 1).sum())
+
+
+@pytest.mark.parametrize("n,hw,c,k", [(128, 32, 64, 128), (128, 8, 256, 512), (6, 16, 128, 256)])
+def test_conv_pair_equals_two_launches(n, hw, c, k):
+    """combat_conv_gemm_pair (a residual block's stride-2 3x3 convolution + its 1x1 stride-2 shortcut over the same input,
+    preact_resnet.py:33-36) against the two combat_conv_gemm launches it replaces: bit-identical outputs and statistics;
+    and a pair that cannot be grouped (a stride-1 3x3 on the DMA kernel + a 1x1) runs as two launches."""
+    import ctypes, math
+    from combat_amd import ops as O_
+    from combat_amd._lib import lib
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.relu(torch.randn(n, hw, hw, c, generator=g(400))).to(bf16).cuda()
+    w3 = (torch.randn(k, c, 3, 3, generator=g(401)) / math.sqrt(9 * c)).cuda().contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(k, c, 1, 1, generator=g(402)) / math.sqrt(c)).cuda().contiguous(memory_format=torch.channels_last)
+    pc3, pc1 = O_.PackedConv(w3, 2, 1, c), O_.PackedConv(w1, 2, 0, c)
+    pc3.pack()
+    pc1.pack()
+    p = hw // 2
+    aff = O_.Affine(torch.rand(k, device="cuda") + 0.5, torch.randn(k, device="cuda"), 0, True, 0.0)
+
+    def make():
+        y3 = torch.zeros(n, p, p, k, dtype=bf16, device="cuda")
+        a3t = torch.zeros_like(y3)
+        y1 = torch.zeros_like(y3)
+        a = O_.conv_args(x, y3, pc3, 0, stats_kind=1, act_dst=a3t, act=aff)
+        rows, _ = O_.conv_stats_layout(a)
+        stt = torch.zeros(rows, 2, k, device="cuda")
+        a.stats = stt.data_ptr()
+        b = O_.conv_args(x, y1, pc1, 0)
+        return a, b, (y3, a3t, y1, stt)
+
+    a, b, sep = make()
+    O_.check(lib.combat_conv_gemm(ctypes.byref(a), st), "a")
+    O_.check(lib.combat_conv_gemm(ctypes.byref(b), st), "b")
+    a2, b2, grp = make()
+    O_.check(lib.combat_conv_gemm_pair(ctypes.byref(b2), ctypes.byref(a2), st), "pair")     # shortcut first, as the engines record it
+    torch.cuda.synchronize()
+    for u, v in zip(sep, grp):
+        assert torch.equal(u, v)
+    assert float(sep[0].float().abs().max()) > 0 and float(sep[2].float().abs().max()) > 0
+    # not groupable: stride-1 3x3 (LDS-DMA halo kernel) + 1x1 stride 1
+    if hw >= 8:
+        w3s = (torch.randn(c, c, 3, 3, generator=g(403)) / math.sqrt(9 * c)).cuda().contiguous(memory_format=torch.channels_last)
+        pcs = O_.PackedConv(w3s, 1, 1, c)
+        pcs.pack()
+        w1s = (torch.randn(c, c, 1, 1, generator=g(404)) / math.sqrt(c)).cuda().contiguous(memory_format=torch.channels_last)
+        pc1s = O_.PackedConv(w1s, 1, 0, c)
+        pc1s.pack()
+        outs = [torch.zeros(n, hw, hw, c, dtype=bf16, device="cuda") for _ in range(4)]
+        O_.check(lib.combat_conv_gemm(ctypes.byref(O_.conv_args(x, outs[0], pcs, 0)), st), "s")
+        O_.check(lib.combat_conv_gemm(ctypes.byref(O_.conv_args(x, outs[1], pc1s, 0)), st), "s1")
+        aa, bb = O_.conv_args(x, outs[2], pcs, 0), O_.conv_args(x, outs[3], pc1s, 0)
+        O_.check(lib.combat_conv_gemm_pair(ctypes.byref(aa), ctypes.byref(bb), st), "pair fallback")
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
