@@ -130,11 +130,20 @@ SIGNATURES = {
     "combat_warp_bwd_input": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_wanet_field_bwd": (C.c_int, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp,
                                          c_vp, c_vp, c_vp, c_vp]),
+    "combat_plan_create": (c_vp, []),
+    "combat_plan_destroy": (None, [c_vp]),
+    "combat_plan_record": (C.c_int, [c_vp, c_i32]),
+    "combat_plan_record_cancel": (C.c_int, []),
+    "combat_plan_size": (c_i32, [c_vp]),
+    "combat_plan_run": (C.c_int, [c_vp, c_i32, c_i32, c_vp, C.POINTER(c_vp), c_i32]),
+    "combat_plan_join": (C.c_int, [c_vp, c_vp, C.POINTER(c_vp), c_i32]),
+    "combat_plan_failed_call": (c_i32, [c_vp]),
 }
 
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x16, TILE_64x128 = 1, 2, 3, 4, 5
 TILE_H256x64, TILE_H128x128, TILE_H128x64, TILE_H64x64, TILE_D128x64, TILE_D128x32 = 6, 7, 8, 9, 10, 11
 TILE_G128x64, TILE_G128x32 = 12, 13
+TILE_D256x64, TILE_C8, TILE_D256W64, TILE_S128x64 = 14, 15, 16, 17
 
 
 class CombatHipError(RuntimeError):

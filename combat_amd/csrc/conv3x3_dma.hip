@@ -60,6 +60,7 @@ struct DmaParams {
     unsigned src_bytes, w_bytes;
     int flavour;                  // epilogue specialisation (conv_dma_epilogue.hpp), -1: generic
     int w_prefetch;               // warm the XCD's L2 with this channel tile's weight rows at kernel start (see the body)
+    int per;                      // weight-stationary kernel: tiles per workgroup
     unsigned long long *stamps;   // profiling builds only
 };
 
@@ -435,6 +436,259 @@ void conv3x3_dma_kernel(const DmaParams p) {
     conv3x3_dma_body<BN, TW, HB, NW, RPW>(p);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight-stationary, persistent variant for C = K = 64 on maps at least 16 wide (PreActResNet18 layer1, the
+// generator's 32 x 32 layers): tile COMBAT_TILE_S128x64.
+//
+// The layer's whole filter bank -- 9 taps x 64 x 64 bf16 = 72 KB -- fits in LDS, so a workgroup loads it ONCE and
+// walks a contiguous range of 128-pixel tiles; the per-tap weight ring of the kernel above, its DMA issue and its
+// barrier per tap disappear, and a tile's main loop is nothing but fragment reads and MFMAs.  These layers move
+// 33-67 MB for 9.7 GFLOP: they are bound by HBM and by what a launch cannot overlap with itself when all its
+// workgroups run one round in lockstep (loads first, MFMAs, stores last -- DESIGN.md section 5).  Here one 512-thread
+// workgroup per CU runs two groups of four waves half a tile apart ("ping-pong"):
+//
+//     half-period h:   group A: MFMAs of its tile      |  group B: epilogue of its previous tile (stores), halo DMA
+//     half-period h+1: group A: epilogue, halo DMA ... |  group B: MFMAs                          of its next tile
+//
+// so each SIMD always has one wave on the matrix pipe and one on the VALU / memory side, the next tile's halo patch
+// lands while the other group computes, and output stores drain under MFMAs.  One barrier per half-period.  The two
+// groups never run their epilogues at the same time, so they share ONE set of wave transposition images:
+// 72 KB weights + 2 x 24 KB halo patches + 34 KB epilogue = 154 KB of the CU's 160.
+// Tile geometry, statistics rows and the fused epilogue are exactly COMBAT_TILE_D128x64's (16 x 8 pixels of one
+// image, one statistics row per wave), so the two kernels are interchangeable launch by launch.
+template <int FLI>   // FLI: index into kEpiFlavours (one epilogue body per kernel instantiation), -1: the generic body
+__device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
+    constexpr int FL = FLI < 0 ? -1 : kEpiFlavours[FLI < 0 ? 0 : FLI];
+    constexpr int BN = 64, TW = 16;
+    using T = TileCfg<128, BN, 4>;
+    using G = DGeo<TW, 4, 32>;
+    using EC = EpiCfg<T>;
+    constexpr int WBYTES = 9 * BN * 128, HBYTES = G::HBYTES, HPW = G::HPW, EPI_OFF = WBYTES + 2 * HBYTES;
+    constexpr int TAB_OFF = EPI_OFF + EC::LDS_BYTES;    // bias | xh_rstd | xh_mean, 64 floats each (see epi_finish_fl)
+    static_assert(G::TI == 1 && G::TH == 8 && G::HWP == 18, "one 16 x 8 patch of one image per tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const combat_conv_args &a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wid >> 2, gw = wid & 3;
+    const int C = a.C, H = a.H, W = a.W;
+    unsigned char *const wlds = smem;
+    unsigned char *const halo = smem + WBYTES + grp * HBYTES;
+
+#ifdef COMBAT_STAMPS     // per wave: 40 cycle stamps (tools/stamps_ws.py)
+#define WS_STAMP(i)                                                                                               \
+    do {                                                                                                          \
+        if (lane == 0 && p.stamps && (i) < 40) p.stamps[(blockIdx.x * 8 + wid) * 40 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define WS_STAMP(i)
+#endif
+    WS_STAMP(0);
+    const int first = blockIdx.x * p.per, left = p.tiles_m - first;
+    const int cnt = left < p.per ? left : p.per;            // tiles of this workgroup (>= 1)
+    const int ng = (cnt - grp + 1) >> 1;                      // ... of this group: first + grp, first + grp + 2, ...
+
+    // Every LDS-DMA of this kernel is issued from inline asm (see the halo patch below for why): resources as four
+    // scalar words, the LDS address through M0.
+    auto rsrc_words = [&](const void *ptr, unsigned bytes) __attribute__((always_inline)) {
+        const unsigned long base = (unsigned long)ptr;
+        u32x4_t w;
+        w[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
+        w[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
+        w[2] = __builtin_amdgcn_readfirstlane(ptr ? bytes : 0u);      // (absent tensor: every load reads zeros)
+        w[3] = 0x00020000u;
+        return w;
+    };
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_t *)smem);
+#define COMBAT_DMA16(rs, lds_addr, voff)                                                         \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory")
+#define COMBAT_DMA4(rs, lds_addr, voff)                                                          \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory")
+    // ---- the filter bank, once: wave w brings rows 8 w .. 8 w + 7 of every tap (dgrad walks the taps mirrored)
+    {
+        const u32x4_t wrs = rsrc_words(a.wpack, p.w_bytes);
+        const int n = wid * 8 + (lane >> 3), slot = lane & 7;
+        const int chunk = (slot - (n & 6)) & 7;
+        const unsigned voff = (unsigned)((n * a.kpad + chunk * 8) * 2);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int tap = a.mode == 0 ? t : 8 - t;
+            COMBAT_DMA16(wrs, lds0 + t * (BN * 128) + wid * 1024, voff + (unsigned)(tap * C * 2));
+        }
+    }
+    // ---- per-channel tables of the epilogue, once: 64 floats each = one 4-byte DMA per table (wave 0)
+    if (wid == 0) {
+        COMBAT_DMA4(rsrc_words(a.bias, BN * 4), lds0 + TAB_OFF, (unsigned)(lane * 4));
+        COMBAT_DMA4(rsrc_words(a.xh_rstd, BN * 4), lds0 + TAB_OFF + BN * 4, (unsigned)(lane * 4));
+        COMBAT_DMA4(rsrc_words(a.xh_mean, BN * 4), lds0 + TAB_OFF + 2 * BN * 4, (unsigned)(lane * 4));
+    }
+    // ---- halo DMA bookkeeping that does not depend on the tile: decoded position + byte offset relative to the
+    // tile's first pixel, with the channel chunk this lane's LDS slot must receive (rotation by halo column)
+    int hdec[HPW], hrel[HPW];
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        const int row = (gw + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
+        const int hx = row % G::HWP, hy = row / G::HWP;
+        const int chunk = (slot - (hx & 6)) & 7;
+        hdec[j] = (row < G::HROWS && hx < TW + 2) ? (hx | (hy << 8)) : -1;
+        hrel[j] = (((hy - 1) * W + hx - 1) * C + chunk * 8) * 2;
+    }
+    int t_img = 0, t_oy = 0, t_ox = 0;
+    auto tile_coords = [&](int k) __attribute__((always_inline)) {   // tile k of this group
+        const int tm = first + grp + 2 * k;
+        const int tx_ = tm % p.tiles_x, r = tm / p.tiles_x;
+        t_ox = tx_ * TW;
+        t_oy = (r % p.tiles_y) * G::TH;
+        t_img = r / p.tiles_y;
+        return tm;
+    };
+    // The DMA is issued from inline asm because the compiler guards the first LDS read behind an LDS-DMA it knows of
+    // with s_waitcnt vmcnt(0) -- here that would park the epilogue (whose transposition image is LDS) until the next
+    // tile's patch has landed, the very latency this schedule hides.  Unknown to the compiler, a DMA only makes its
+    // own counted waits conservative (the counter is in order); the explicit waits below order the patch's readers.
+    const u32x4_t srs = rsrc_words(a.src, p.src_bytes);
+    const unsigned halo_lds = lds0 + WBYTES + grp * HBYTES + gw * 1024;
+    auto issue_halo = [&]() __attribute__((always_inline)) {          // of the tile tile_coords() was last called for
+        const int org = ((t_img * H + t_oy) * W + t_ox) * C * 2;
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) {
+            const int d = hdec[j];
+            const bool ok = d >= 0 && (unsigned)(t_oy + (d >> 8) - 1) < (unsigned)H && (unsigned)(t_ox + (d & 255) - 1) < (unsigned)W;
+            const unsigned voff = ok ? (unsigned)(org + hrel[j]) : kOob;
+            COMBAT_DMA16(srs, halo_lds + j * 4096, voff);
+        }
+    };
+#undef COMBAT_DMA4
+
+    // ---- per-lane fragment read offsets (as in the kernel above, a group's wave in place of the workgroup's)
+    int pa[2][T::FM][3];
+#pragma unroll
+    for (int j = 0; j < T::FM; ++j) {
+        const int pj = gw * 32 + j * 16 + (lane & 15);
+        const int tx = pj & (TW - 1), ty = pj >> 4;
+        const int r0 = ty * G::HWP + tx;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int s0 = ((lane >> 4) + ((tx + dx) & 6)) & 7;
+            pa[0][j][dx] = (r0 + dx) * 128 + s0 * 16;
+            pa[1][j][dx] = (r0 + dx) * 128 + (s0 ^ 4) * 16;
+        }
+    }
+    int wa[2];
+    {
+        const int n = lane & 15;
+        const int s0 = ((lane >> 4) + (n & 6)) & 7;
+        wa[0] = n * 128 + s0 * 16;
+        wa[1] = n * 128 + (s0 ^ 4) * 16;
+    }
+
+    const unsigned dst_bytes = (unsigned)(a.N * p.PQ) * (unsigned)a.K * 2u;
+    auto tile_row_off = [&](int row) -> long {
+        const int tx = row & (TW - 1), ty = (row >> 4) & (G::TH - 1);
+        return (long)((t_img * H + t_oy + ty) * W + t_ox + tx) * a.K;
+    };
+    EpiRegs<T> epi;
+    f32x4_t acc[T::FN][T::FM];
+
+    auto read_frags = [&](bf16x8_t (&fp)[T::FM], bf16x8_t (&fw)[T::FN], auto t_tag, auto ks_tag) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_tag)::value, ks = decltype(ks_tag)::value;
+        constexpr int dy = t / 3, dx = t % 3;
+        const unsigned char *hb = halo + dy * G::HWP * 128;
+        const unsigned char *wb = wlds + t * (BN * 128);
+#pragma unroll
+        for (int j = 0; j < T::FM; ++j) fp[j] = *reinterpret_cast<const bf16x8_t *>(hb + pa[ks][j][dx]);
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i) fw[i] = *reinterpret_cast<const bf16x8_t *>(wb + wa[ks] + i * 2048);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_frags = [&](const bf16x8_t (&fp)[T::FM], const bf16x8_t (&fw)[T::FN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fp[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- prologue: the filter bank and this group's first halo patch must have landed before anyone reads LDS; the
+    // first tile's epilogue operands are fetched behind that wait and land under its MFMAs
+    int tm_cur = 0;
+    if (ng > 0) {
+        tm_cur = tile_coords(0);
+        issue_halo();
+    }
+    WS_STAMP(1);
+    wait_vm_lgkm0<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    if (ng > 0) {
+        epi_init<T>(epi, lane, gw, 0, tile_row_off);
+        epi_fetch<T>(epi, a, dst_bytes, lane, 0);
+    }
+    block_barrier();
+    // ---- group B runs half a period behind group A: one barrier interval = one half-period, in which one group
+    // computes a tile and the other finishes its previous one.  Both groups run the SAME straight-line loop body
+    // (compute, barrier, finish + prefetch, barrier), so the loop-carried epilogue operands stay in their registers.
+    WS_STAMP(2);
+    if (grp == 1) block_barrier();
+    WS_STAMP(3);
+    for (int k = 0; k < ng; ++k) {
+#pragma unroll
+        for (int i = 0; i < T::FN; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        {
+            bf16x8_t fpA[T::FM], fwA[T::FN], fpB[T::FM], fwB[T::FN];
+            read_frags(fpA, fwA, I0{}, I0{});
+#define COMBAT_WS_POS(t)                                                                       \
+    {                                                                                          \
+        read_frags(fpB, fwB, std::integral_constant<int, t>{}, I1{});                          \
+        mfma_frags(fpA, fwA);                                                                  \
+        if (t < 8) read_frags(fpA, fwA, std::integral_constant<int, (t + 1) % 9>{}, I0{});     \
+        mfma_frags(fpB, fwB);                                                                  \
+    }
+            COMBAT_WS_POS(0) COMBAT_WS_POS(1) COMBAT_WS_POS(2) COMBAT_WS_POS(3) COMBAT_WS_POS(4)
+            COMBAT_WS_POS(5) COMBAT_WS_POS(6) COMBAT_WS_POS(7) COMBAT_WS_POS(8)
+#undef COMBAT_WS_POS
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads are back: its patch may be overwritten
+        WS_STAMP(4 + 6 * k);
+        block_barrier();
+        WS_STAMP(5 + 6 * k);
+        const int tm_done = tm_cur;
+        const bool more = k + 1 < ng;
+        epi_touch<T>(epi);   // (the operand fetches have landed: say so before the DMA below enters the wait counts)
+        if (more) {          // the patch of this group's next tile lands while the other group computes
+            tm_cur = tile_coords(k + 1);
+            issue_halo();
+        }
+        WS_STAMP(6 + 6 * k);
+        // (the wait for the next patch sits in front of this tile's stores: nothing else is in flight there)
+        epi_finish_fl<T, FL>(epi, smem + EPI_OFF, acc, a, dst_bytes, lane, gw, 0, (long)tm_done * 4 + gw, false, p.PQ,
+                             (const lds_f32_t *)(smem + TAB_OFF), [&]() __attribute__((always_inline)) {
+                                 __builtin_amdgcn_sched_barrier(0);
+                                 WS_STAMP(7 + 6 * k);
+                                 wait_vm_lgkm0<0>();
+                                 WS_STAMP(8 + 6 * k);
+                                 __builtin_amdgcn_sched_barrier(0);
+                             });
+        if (more) {
+            __builtin_amdgcn_sched_barrier(0);
+            epi_init<T>(epi, lane, gw, 0, tile_row_off);
+            epi_fetch<T>(epi, a, dst_bytes, lane, 0);
+        }
+        WS_STAMP(9 + 6 * k);
+        block_barrier();
+    }
+    // every wave executes the same number of barriers: A ran 1 + 2 ceil(cnt / 2), B 2 + 2 floor(cnt / 2)
+    if ((cnt & 1) == grp) block_barrier();
+#undef WS_STAMP
+}
+
+template <int FLI>
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const DmaParams p) { conv3x3_ws_body<FLI>(p); }
+
 int geo_tw(const combat_conv_args *a) {
     if (a->W >= 16) return (a->W % 16 == 0 && a->H % 8 == 0) ? 16 : 0;
     if (a->W == 8) return a->H == 8 ? 8 : 0;
@@ -525,18 +779,61 @@ int tiles_m_of(const combat_conv_args *a, int bm = 128) {
     return (a->W / tw) * (a->H / th) * ((a->N + ti - 1) / ti);
 }
 
+// weight-stationary persistent kernel: the whole filter bank in LDS (C = K = 64), 16-wide tiles, and at least two
+// tiles per CU (with one, there is nothing to overlap: the ring kernel's three co-resident workgroups do better)
+constexpr int kWsSmem = 9 * 64 * 128 + 2 * DGeo<16, 4, 32>::HBYTES + EpiCfg<TileCfg<128, 64, 4>>::LDS_BYTES + 3 * 64 * 4;
+bool ws_applicable(const combat_conv_args *a) {
+    if (a->C != 64 || a->K != 64 || !applicable(a, 64) || geo_tw(a) != 16 || a->H % 8) return false;
+    if (epi_flavour_of(*a) < 0) return false;   // (the generic epilogue body does not fit beside the persistent state: 44 spills)
+    return (long)tiles_m_of(a) >= 2 * 256 || a->tile == COMBAT_TILE_S128x64;
+}
+
+template <int FLI>
+int launch_ws_fl(const DmaParams &p, int blocks, hipStream_t st) {
+    auto kern = conv3x3_ws_kernel<FLI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kWsSmem) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), kWsSmem, st, p);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+int launch_ws(const combat_conv_args *a, hipStream_t st) {
+    DmaParams p;
+    fill<16, 4, 32>(a, 64, p);
+    const int cus = 256;
+    p.per = (p.tiles_m + cus - 1) / cus;
+    if (p.per < 1) p.per = 1;
+    const int blocks = (p.tiles_m + p.per - 1) / p.per;
+    switch (p.flavour) {
+        case 0: return launch_ws_fl<0>(p, blocks, st);
+        case 1: return launch_ws_fl<1>(p, blocks, st);
+        case 2: return launch_ws_fl<2>(p, blocks, st);
+        case 3: return launch_ws_fl<3>(p, blocks, st);
+        case 4: return launch_ws_fl<4>(p, blocks, st);
+        default: return COMBAT_EINVAL;
+    }
+    static_assert(kNumEpiFlavours == 5, "one case per flavour");
+}
+
 }  // namespace
 
 // tile id the DMA kernel would use for these args (an explicit a->tile is honoured), or 0.
 // Measured on MI355X (profiles/r01_c_dma_tile_sweep.txt): wherever it applies it beats the
 // register-staged halo tiles (1.3-1.9x on the PreActResNet18 layer shapes).
 int conv3x3d_pick(const combat_conv_args *a) {
+    if (a->tile == COMBAT_TILE_S128x64) return ws_applicable(a) ? a->tile : 0;
     if (a->tile) {
         const int bn = tile_bn(a->tile);
         if (a->tile == COMBAT_TILE_D256W64 && geo_tw(a) != 16) return 0;
         return bn && applicable(a, bn) && geo_th(a, tile_bm(a->tile)) ? a->tile : 0;
     }
     if (!applicable(a, 64)) return applicable(a, 32) ? COMBAT_TILE_D128x32 : 0;
+    if (ws_applicable(a) && !getenv("COMBAT_NO_WS")) return COMBAT_TILE_S128x64;
     // skinny layers: 32-channel tiles double the workgroup count when 64-channel tiles give no more than
     // one workgroup per CU (a workgroup alone on a CU issues in order: DMA pieces ~100 cycles each, then
     // fragment reads, then MFMAs; a second one fills those gaps: 5-6 % on the 256-tile shapes).  (256-pixel tiles -- eight waves, half the weight DMA per MFMA -- exist for explicit requests
@@ -548,6 +845,7 @@ int conv3x3d_pick(const combat_conv_args *a) {
 }
 
 int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {
+    if (tile == COMBAT_TILE_S128x64) tile = COMBAT_TILE_D128x64;     // same tiles, same rows
     const int bn = tile_bn(tile);
     if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
     const int tw = geo_tw(a), bm = tile_bm(tile);
@@ -559,6 +857,7 @@ int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *r
 }
 
 int conv3x3d_launch(const combat_conv_args *a, int tile, hipStream_t st) {
+    if (tile == COMBAT_TILE_S128x64) return ws_applicable(a) ? launch_ws(a, st) : COMBAT_EINVAL;
     const int bn = tile_bn(tile);
     if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
     const int tw = geo_tw(a);

@@ -16,6 +16,15 @@
 
 constexpr unsigned kDmaOob = 0x40000000u;  // buffer offset beyond every tensor on this path: reads as zeros
 
+typedef __attribute__((address_space(3))) float lds_f32_t;   // (an LDS pointer the compiler KNOWS is one: ds_read, not flat_load)
+__device__ __forceinline__ void load8f_lds(const lds_f32_t *p, float (&v)[8]) {
+    typedef __attribute__((address_space(3))) f32x4_t lds_f32x4_t;
+    const f32x4_t a = *reinterpret_cast<const lds_f32x4_t *>(p);
+    const f32x4_t b = *reinterpret_cast<const lds_f32x4_t *>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+
 template <typename T>
 struct EpiCfg {
     static constexpr int NC = T::NC;              // 16-byte chunks per dst row of the tile
@@ -67,6 +76,17 @@ __device__ __forceinline__ void epi_fetch(EpiRegs<T> &r, const combat_conv_args 
         r.t_sc[h] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_sc, tb + 16 * h, 0, 0));
         r.t_sh[h] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_sh, tb + 16 * h, 0, 0));
     }
+}
+
+// Make the compiler wait for epi_fetch()'s loads HERE (an empty asm that "uses" every fetched register).  Its wait
+// counts track only VGPR-destination loads: a use of these registers placed after younger LDS-DMA instructions gets
+// a vmcnt(0..3) that also waits for those DMAs.  Called before such DMAs are issued, the wait costs nothing (the
+// fetches are a main loop old) and later uses need none.
+template <typename T>
+__device__ __forceinline__ void epi_touch(EpiRegs<T> &r) {
+#pragma unroll
+    for (int q = 0; q < EpiCfg<T>::EQ; ++q) asm volatile("" : "+v"(r.e_pre[q]), "+v"(r.e_x[q]), "+v"(r.e_post[q]));
+    asm volatile("" : "+v"(r.t_sc[0]), "+v"(r.t_sc[1]), "+v"(r.t_sh[0]), "+v"(r.t_sh[1]));
 }
 
 // ---- epilogue flavours.  epi_finish's feature tests (which operand tensors exist, which mask form, which
@@ -136,10 +156,21 @@ inline int epi_flavour_of(const combat_conv_args &a) {
 // entirely outside the tensor and owns no row); ragged = the wave
 // may own rows outside the tensor (their statistics count as zeros).
 // FL >= 0: the launch's feature bits, known at compile time; FL < 0: read from the arguments.
-template <typename T, int FL>
+struct EpiNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// pre_store(): called once, after the last use of the fetched operands and before the first global store (a
+// persistent caller waits for its in-flight LDS-DMA there: behind the stores, the in-order counter could only be
+// waited down together with them)
+template <typename T, int FL, typename PreStore = EpiNoHook>
 __device__ __forceinline__ void epi_finish_fl(EpiRegs<T> &er, unsigned char *smem, const f32x4_t (&acc)[T::FN][T::FM],
                                               const combat_conv_args &a, unsigned dst_bytes, int lane, int wid, int n0,
-                                              long stats_row, bool ragged, int PQ) {
+                                              long stats_row, bool ragged, int PQ, const lds_f32_t *lds_tabs = nullptr,
+                                              PreStore pre_store = PreStore()) {
+    // lds_tabs: the per-channel tables this body would fetch from global memory (bias, xh_rstd, xh_mean: K floats
+    // each, in that order; absent ones as zeros), staged in LDS by a persistent caller -- a global load issued here,
+    // behind that caller's in-flight LDS-DMA, could only be waited for together with the DMA (in-order vmcnt)
     constexpr int NC = EpiCfg<T>::NC, EQ = EpiCfg<T>::EQ, EPW = EpiCfg<T>::EPW;
     constexpr bool RT = FL < 0;
     const int fl = RT ? epi_flags_of(a) : (FL | (epi_flags_of(a) & kEpiRuntime));
@@ -167,10 +198,18 @@ __device__ __forceinline__ void epi_finish_fl(EpiRegs<T> &er, unsigned char *sme
         tsh[e] = er.t_sh[e >> 2][e & 3];
         bias8[e] = hrs[e] = hmn[e] = 0.f;
     }
-    if (has_bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
-    if (kind2 && !per_image) {
-        load8f(a.xh_rstd + n, hrs);
-        load8f(a.xh_mean + n, hmn);
+    if (lds_tabs) {
+        if (has_bias) load8f_lds(lds_tabs + n, bias8);
+        if (kind2 && !per_image) {
+            load8f_lds(lds_tabs + K + n, hrs);
+            load8f_lds(lds_tabs + 2 * K + n, hmn);
+        }
+    } else {
+        if (has_bias) load8f(a.bias + n, bias8);   // the rarer tables are not worth registers during the main loop
+        if (kind2 && !per_image) {
+            load8f(a.xh_rstd + n, hrs);
+            load8f(a.xh_mean + n, hmn);
+        }
     }
     const float mslope = a.mask_slope, aslope = a.act_slope;
     float s1[8], s2[8];
@@ -252,6 +291,7 @@ __device__ __forceinline__ void epi_finish_fl(EpiRegs<T> &er, unsigned char *sme
             }
         }
     }
+    pre_store();
     if (has_dst) {
 #pragma unroll
         for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed[q], r_dst, er.evoff[q], 0, 0);

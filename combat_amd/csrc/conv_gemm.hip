@@ -21,6 +21,7 @@
 // networks/models.py:275-314, defenses/frequency_based/model.py:13-39, together with the
 // normalisation/activation/residual element-wise ops around them.
 #include "conv_common.hpp"
+#include "plan.hpp"
 
 namespace {
 
@@ -313,7 +314,7 @@ int pick_tile(const combat_conv_args *a) {
         return conv_gather_dma_bn(a) == 64 ? COMBAT_TILE_G128x64 : COMBAT_TILE_G128x32;
     if (const int halo = conv3x3_pick(a)) return halo;   // 3x3 / stride 1 with the patch held in LDS
     if ((a->tile >= COMBAT_TILE_H256x64 && a->tile < COMBAT_TILE_G128x64) || a->tile == COMBAT_TILE_D256x64 ||
-        a->tile == COMBAT_TILE_D256W64)
+        a->tile == COMBAT_TILE_D256W64 || a->tile == COMBAT_TILE_S128x64)
         return 0;   // a 3x3 tile was forced but does not apply
     if ((a->tile == 0 || a->tile == COMBAT_TILE_C8) && conv_c8_ok(a)) return COMBAT_TILE_C8;
     if (a->tile == COMBAT_TILE_C8) return 0;
@@ -354,6 +355,7 @@ extern "C" int combat_conv_stats_granule(int tile) {
         case COMBAT_TILE_G128x32:
         case COMBAT_TILE_C8:
         case COMBAT_TILE_D256W64:
+        case COMBAT_TILE_S128x64:
         case COMBAT_TILE_D256x64: return 32;
         case COMBAT_TILE_64x64:
         case COMBAT_TILE_64x128:
@@ -365,7 +367,8 @@ extern "C" int combat_conv_stats_granule(int tile) {
 extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows, int32_t *rows_per_image) {
     if (!a || !rows || !rows_per_image) return COMBAT_EINVAL;
     const int tile = pick_tile(a);
-    if ((tile >= COMBAT_TILE_H256x64 && tile < COMBAT_TILE_G128x64) || tile == COMBAT_TILE_D256x64 || tile == COMBAT_TILE_D256W64)
+    if ((tile >= COMBAT_TILE_H256x64 && tile < COMBAT_TILE_G128x64) || tile == COMBAT_TILE_D256x64 || tile == COMBAT_TILE_D256W64 ||
+        tile == COMBAT_TILE_S128x64)
         return conv3x3_stats_layout(a, tile, rows, rows_per_image);
     const int gran = combat_conv_stats_granule(tile);
     if (gran <= 0) return COMBAT_EINVAL;
@@ -388,6 +391,7 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream);
 // Two convolutions with no data dependence between them (neither reads what the other writes): one launch when both take
 // the gather kernel with the same channel tile and unsplit reductions, otherwise a, then b.
 extern "C" int combat_conv_gemm_pair(const combat_conv_args *a, const combat_conv_args *b, void *stream) {
+    COMBAT_PLAN_HOOK(combat_conv_gemm_pair, a, b);
     if (!a || !b) return COMBAT_EINVAL;
     const int ta = pick_tile(a), tb = pick_tile(b);
     const bool gather = (ta == COMBAT_TILE_G128x64 || ta == COMBAT_TILE_G128x32) && ta == tb;
@@ -402,6 +406,7 @@ extern "C" int combat_conv_gemm_pair(const combat_conv_args *a, const combat_con
 }
 
 extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
+    COMBAT_PLAN_HOOK(combat_conv_gemm, a);
     if (!a || !a->src || !a->wpack || (!a->dst && !a->act_dst)) return COMBAT_EINVAL;
     if (a->act_dst && (!a->act_scale || !a->act_shift)) return COMBAT_EINVAL;
     if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->P <= 0 || a->Q <= 0) return COMBAT_EINVAL;
@@ -434,7 +439,7 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     const int tile = pick_tile(a);
     if (tile == COMBAT_TILE_C8) return conv_c8_launch(a, st);
     if (tile == COMBAT_TILE_G128x64 || tile == COMBAT_TILE_G128x32) return conv_gather_dma_launch(a, st);
-    if (tile == COMBAT_TILE_D256W64) return conv3x3_launch(a, tile, st);
+    if (tile == COMBAT_TILE_D256W64 || tile == COMBAT_TILE_S128x64) return conv3x3_launch(a, tile, st);
     if (tile >= COMBAT_TILE_H256x64) return conv3x3_launch(a, tile, st);
     switch (tile) {
         case COMBAT_TILE_128x128: return launch<128, 128>(p, st);

@@ -14,6 +14,7 @@
 // conv_gemm.hip; the prologue recomputes the normalised/activated conv input from the saved
 // pre-normalisation tensor, as the forward kernel does.
 #include "conv_common.hpp"
+#include "plan.hpp"
 
 namespace {
 
@@ -486,6 +487,7 @@ extern "C" int64_t combat_conv_wgrad_workspace_bytes(const combat_wgrad_args *a)
 }
 
 extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
+    COMBAT_PLAN_HOOK(combat_conv_wgrad, a);
     if (!a || !a->src || !a->dy || !a->dw) return COMBAT_EINVAL;
     if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->P <= 0 || a->Q <= 0) return COMBAT_EINVAL;
     if (a->C < 8 || (a->C & 7) || a->K < 8 || (a->K & 7)) return COMBAT_EINVAL;

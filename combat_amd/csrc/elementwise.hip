@@ -3,6 +3,7 @@
 // All HBM-bound; every global access is a 16-byte (8 x bf16 / 4 x fp32) vector where the layout
 // allows it.
 #include "common.hpp"
+#include "plan.hpp"
 
 namespace {
 
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(256) void log_terms_kernel(const float *__restrict_
 extern "C" int combat_pack_weights(const float *w, int32_t K, int32_t taps, int32_t c_real, int32_t C,
                                    int32_t dup_hilo, void *wf, int32_t rows_pad_f, int32_t kpad_f, void *wd,
                                    int32_t rows_pad_d, int32_t kpad_d, void *stream) {
+    COMBAT_PLAN_HOOK(combat_pack_weights, w, K, taps, c_real, C, dup_hilo, wf, rows_pad_f, kpad_f, wd, rows_pad_d, kpad_d);
     if (!w || !wf || K <= 0 || taps <= 0 || c_real <= 0 || C < c_real || (C & 7)) return COMBAT_EINVAL;
     if (rows_pad_f < K || kpad_f < taps * C || (kpad_f & 63)) return COMBAT_EINVAL;
     const int Kc = (K + 7) & ~7;
@@ -501,6 +503,7 @@ extern "C" int combat_pack_weights(const float *w, int32_t K, int32_t taps, int3
 }
 
 extern "C" int combat_pack_weights_batch(const combat_pack_desc *descs, int32_t n, void *stream) {
+    COMBAT_PLAN_HOOK(combat_pack_weights_batch, descs, n);
     if (!descs || n < 0) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(512, (unsigned)n), dim3(256), 0, as_stream(stream), descs);
@@ -509,6 +512,7 @@ extern "C" int combat_pack_weights_batch(const combat_pack_desc *descs, int32_t 
 }
 
 extern "C" int combat_image_to_c8(const float *x, int32_t n, int32_t hw, void *out_c8, void *stream) {
+    COMBAT_PLAN_HOOK(combat_image_to_c8, x, n, hw, out_c8);
     if (!x || !out_c8 || n < 0 || hw <= 0) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     hipLaunchKernelGGL(image_to_c8_kernel, dim3(grid_for((long)n * hw * hw)), dim3(256), 0, as_stream(stream), x, n,
@@ -519,6 +523,7 @@ extern "C" int combat_image_to_c8(const float *x, int32_t n, int32_t hw, void *o
 
 extern "C" int combat_nhwc_to_nchw_f32(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, int32_t c,
                                        float *out, void *stream) {
+    COMBAT_PLAN_HOOK(combat_nhwc_to_nchw_f32, x, n, h, w, C, c, out);
     if (!x || !out || n < 0 || h <= 0 || w <= 0 || c <= 0 || c > C) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)n * c * h * w)), dim3(256), 0, as_stream(stream),
@@ -529,6 +534,7 @@ extern "C" int combat_nhwc_to_nchw_f32(const void *x, int32_t n, int32_t h, int3
 
 extern "C" int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, int32_t h, int32_t w, int32_t C,
                                         void *out, void *stream) {
+    COMBAT_PLAN_HOOK(combat_nchw_to_nhwc_bf16, x, n, c, h, w, C, out);
     if (!x || !out || n < 0 || h <= 0 || w <= 0 || c <= 0 || c > C || (C & 7)) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)n * h * w * C)), dim3(256), 0, as_stream(stream), x, n,
@@ -538,6 +544,7 @@ extern "C" int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, in
 }
 
 extern "C" int combat_memset_zero(void *ptr, int64_t bytes, void *stream) {
+    COMBAT_PLAN_HOOK(combat_memset_zero, ptr, bytes);
     if (!ptr || bytes < 0) return COMBAT_EINVAL;
     if (bytes == 0) return COMBAT_OK;
     return hipMemsetAsync(ptr, 0, (size_t)bytes, as_stream(stream)) == hipSuccess ? COMBAT_OK : COMBAT_ELAUNCH;
@@ -545,6 +552,7 @@ extern "C" int combat_memset_zero(void *ptr, int64_t bytes, void *stream) {
 
 extern "C" int combat_log_terms(const float *x, const float *xb, const float *mse_partial, int32_t n, int32_t hw,
                                 const float *detector_logits, double *acc2, double *hits, void *stream) {
+    COMBAT_PLAN_HOOK(combat_log_terms, x, xb, mse_partial, n, hw, detector_logits, acc2, hits);
     if (!x || !xb || !acc2 || n <= 0 || hw < 2) return COMBAT_EINVAL;
     hipLaunchKernelGGL(log_terms_kernel, dim3(3 * n), dim3(256), 0, as_stream(stream), x, xb, mse_partial, 3 * n, n, hw,
                        detector_logits, n, acc2, hits);
@@ -553,6 +561,7 @@ extern "C" int combat_log_terms(const float *x, const float *xb, const float *ms
 }
 
 extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream) {
+    COMBAT_PLAN_HOOK(combat_colsum, x, rows, C, c_out, out);
     if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || c_out <= 0 || c_out > C) return COMBAT_EINVAL;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(out, 0, sizeof(float) * c_out, st) != hipSuccess) return COMBAT_ELAUNCH;
@@ -565,6 +574,7 @@ extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_o
 }
 
 extern "C" int combat_maxpool2(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, void *out, void *stream) {
+    COMBAT_PLAN_HOOK(combat_maxpool2, x, n, h, w, C, out);
     if (!x || !out || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || (C & 7)) return COMBAT_EINVAL;
     hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for((long)n * (h / 2) * (w / 2) * (C / 8))), dim3(256), 0,
                        as_stream(stream), reinterpret_cast<const __bf16 *>(x), n, h, w, C,
@@ -575,6 +585,7 @@ extern "C" int combat_maxpool2(const void *x, int32_t n, int32_t h, int32_t w, i
 
 extern "C" int combat_elu_affine(const void *x, int64_t rows, int32_t C, const float *scale, const float *shift,
                                  void *out, void *stream) {
+    COMBAT_PLAN_HOOK(combat_elu_affine, x, rows, C, scale, shift, out);
     if (!x || !out || !scale || !shift || rows <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     hipLaunchKernelGGL(elu_affine_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), (long)rows, C, scale, shift,
@@ -599,6 +610,7 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const uint4 *__restrict_
 }  // namespace
 
 extern "C" int combat_relu_mask(const void *g, const void *act, int64_t elements, void *out, void *stream) {
+    COMBAT_PLAN_HOOK(combat_relu_mask, g, act, elements, out);
     if (!g || !act || !out || elements <= 0 || (elements & 7)) return COMBAT_EINVAL;
     hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(elements / 8, 8192)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const uint4 *>(g), reinterpret_cast<const uint4 *>(act), (long)(elements / 8),
@@ -609,6 +621,7 @@ extern "C" int combat_relu_mask(const void *g, const void *act, int64_t elements
 
 extern "C" int combat_affine_act(const void *x, int64_t rows, int32_t C, const float *scale, const float *shift,
                                  int64_t group_rows, float slope, void *out, void *stream) {
+    COMBAT_PLAN_HOOK(combat_affine_act, x, rows, C, scale, shift, group_rows, slope, out);
     if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || group_rows < 0) return COMBAT_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return COMBAT_EINVAL;
     hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(rows * (C / 8), 8192)), dim3(256), 0, as_stream(stream),
@@ -621,6 +634,7 @@ extern "C" int combat_affine_act(const void *x, int64_t rows, int32_t C, const f
 extern "C" int combat_unet_up_fwd(const void *y, const float *sy, const float *ty, const void *s, const float *ss,
                                   const float *ts, int32_t N, int32_t H, int32_t W, int32_t C, void *out,
                                   void *stream) {
+    COMBAT_PLAN_HOOK(combat_unet_up_fwd, y, sy, ty, s, ss, ts, N, H, W, C, out);
     if (!y || !sy || !ty || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     if (s && (!ss || !ts)) return COMBAT_EINVAL;
     UpArgs a{reinterpret_cast<const __bf16 *>(y), reinterpret_cast<const __bf16 *>(s), sy, ty, ss, ts, N, H, W, C,
@@ -633,6 +647,7 @@ extern "C" int combat_unet_up_fwd(const void *y, const float *sy, const float *t
 
 extern "C" int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N, int32_t H, int32_t W, int32_t C,
                                   void *du, void *stream) {
+    COMBAT_PLAN_HOOK(combat_unet_up_bwd, d_out, out, N, H, W, C, du);
     if (!d_out || !out || !du || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     hipLaunchKernelGGL(unet_up_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8), 8192)), dim3(256), 0,
                        as_stream(stream), reinterpret_cast<const __bf16 *>(d_out), reinterpret_cast<const __bf16 *>(out),
@@ -644,6 +659,7 @@ extern "C" int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N,
 extern "C" int combat_sgd_nesterov(const void *ptrs, const int64_t *sizes, int32_t count, int64_t max_size, float lr,
                                    float momentum, float weight_decay, float grad_scale, int32_t first_step,
                                    void *stream) {
+    COMBAT_PLAN_HOOK(combat_sgd_nesterov, ptrs, sizes, count, max_size, lr, momentum, weight_decay, grad_scale, first_step);
     if (!ptrs || !sizes || count <= 0 || max_size <= 0) return COMBAT_EINVAL;
     long bx = (max_size + 255) / 256;
     if (bx > 4096) bx = 4096;
@@ -655,6 +671,7 @@ extern "C" int combat_sgd_nesterov(const void *ptrs, const int64_t *sizes, int32
 
 extern "C" int combat_linear_nhwc(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, const float *Wt,
                                   const float *b, int32_t classes, float *logits, void *stream) {
+    COMBAT_PLAN_HOOK(combat_linear_nhwc, x, n, h, w, C, Wt, b, classes, logits);
     if (!x || !Wt || !b || !logits || n <= 0 || h <= 0 || w <= 0 || C <= 0 || classes <= 0) return COMBAT_EINVAL;
     hipLaunchKernelGGL(linear_nhwc_kernel, dim3(n), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), h, w, C, Wt, b, classes, logits);

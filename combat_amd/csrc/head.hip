@@ -5,6 +5,7 @@
 // resnet.py:93-96) and nn.CrossEntropyLoss + argmax accuracy counters (train_generator.py:162,
 // 207,231,251,262-267).
 #include "common.hpp"
+#include "plan.hpp"
 
 namespace {
 
@@ -145,6 +146,7 @@ extern "C" int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t 
                                int32_t classes, const int64_t *targets, float loss_weight, float *pooled,
                                float *logits, float *loss_sum, int32_t *correct, const int64_t *targets2,
                                int32_t *correct2, void *stream) {
+    COMBAT_PLAN_HOOK(combat_head_fwd, feat, n, hw, C, W, b, classes, targets, loss_weight, pooled, logits, loss_sum, correct, targets2, correct2);
     if (!feat || !W || !b || !logits || n <= 0 || hw < 4 || (hw & 3) || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     if (classes <= 0 || classes > kMaxClasses) return COMBAT_EINVAL;
     const int in = C * (hw / 4) * (hw / 4);
@@ -167,6 +169,7 @@ extern "C" int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t 
 extern "C" int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32_t C, const float *W,
                                int32_t classes, const float *logits, const int64_t *targets, float loss_weight,
                                float *dlogits, void *d_feat, float *dW, float *db, void *stream) {
+    COMBAT_PLAN_HOOK(combat_head_bwd, pooled, n, hw, C, W, classes, logits, targets, loss_weight, dlogits, d_feat, dW, db);
     if (!W || !logits || !targets || !dlogits || n <= 0 || hw < 4 || (hw & 3) || C <= 0 || (C & 7))
         return COMBAT_EINVAL;
     if (classes <= 0 || classes > kMaxClasses) return COMBAT_EINVAL;

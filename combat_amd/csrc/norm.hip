@@ -6,6 +6,7 @@
 // (classifier_models/preact_resnet.py:20,22,33,36; resnet.py:21,23,29), nn.InstanceNorm2d forward
 // statistics and backward (networks/models.py:278-313).
 #include "common.hpp"
+#include "plan.hpp"
 
 namespace {
 
@@ -823,6 +824,7 @@ extern "C" int combat_norm_finalize(const float *partials, int32_t groups, int32
                                     float *rstd, float *scale, float *shift, float *running_mean,
                                     float *running_var, float momentum, int64_t *num_batches_tracked,
                                     float *scratch, int64_t scratch_bytes, void *stream) {
+    COMBAT_PLAN_HOOK(combat_norm_finalize, partials, groups, rows_per_group, C, count, eps, gamma, beta, mean, rstd, scale, shift, running_mean, running_var, momentum, num_batches_tracked, scratch, scratch_bytes);
     if (!partials || groups <= 0 || rows_per_group <= 0 || C <= 0 || count <= 0.f) return COMBAT_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return COMBAT_EINVAL;
     if (running_mean && groups != 1) return COMBAT_EINVAL;
@@ -842,6 +844,7 @@ extern "C" int combat_norm_bwd_finalize(const float *partials, int32_t groups, i
                                         float count, const float *gamma, const float *mean, const float *rstd,
                                         float *ca, float *cb, float *cc, float *dgamma, float *dbeta,
                                         float *scratch, int64_t scratch_bytes, void *stream) {
+    COMBAT_PLAN_HOOK(combat_norm_bwd_finalize, partials, groups, rows_per_group, C, count, gamma, mean, rstd, ca, cb, cc, dgamma, dbeta, scratch, scratch_bytes);
     if (!partials || !mean || !rstd || !ca || !cb || !cc) return COMBAT_EINVAL;
     if (groups <= 0 || rows_per_group <= 0 || C <= 0 || count <= 0.f) return COMBAT_EINVAL;
     if ((dgamma || dbeta) && groups != 1) return COMBAT_EINVAL;
@@ -892,6 +895,7 @@ extern "C" int combat_norm_act_fused(const void *x, const float *partials, int32
                                      float *running_mean, float *running_var, float momentum,
                                      int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes, void *act,
                                      void *stream) {
+    COMBAT_PLAN_HOOK(combat_norm_act_fused, x, partials, groups, rows_per_group, px_per_group, C, eps, slope, gamma, beta, mean, rstd, scale, shift, running_mean, running_var, momentum, num_batches_tracked, scratch, scratch_bytes, act);
     return norm_act_fused_launch(x, partials, groups, rows_per_group, px_per_group, C, eps, slope, gamma, beta, mean, rstd,
                                  scale, shift, running_mean, running_var, momentum, num_batches_tracked, scratch,
                                  scratch_bytes, nullptr, nullptr, nullptr, act, stream);
@@ -904,6 +908,7 @@ extern "C" int combat_norm_add_act_fused(const void *x, const float *partials, i
                                          int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes,
                                          const void *add, const float *add_scale, const float *add_shift, void *act,
                                          void *stream) {
+    COMBAT_PLAN_HOOK(combat_norm_add_act_fused, x, partials, groups, rows_per_group, px_per_group, C, eps, slope, gamma, beta, mean, rstd, scale, shift, running_mean, running_var, momentum, num_batches_tracked, scratch, scratch_bytes, add, add_scale, add_shift, act);
     if (!add) return COMBAT_EINVAL;
     return norm_act_fused_launch(x, partials, groups, rows_per_group, px_per_group, C, eps, slope, gamma, beta, mean, rstd,
                                  scale, shift, running_mean, running_var, momentum, num_batches_tracked, scratch,
@@ -914,6 +919,7 @@ extern "C" int combat_unet_up_fused(const void *y, const float *partials, int32_
                                     const float *ss, const float *ts, int32_t N, int32_t H, int32_t W, int32_t C,
                                     float eps, float *mean, float *rstd, float *scale, float *shift, void *out,
                                     void *stream) {
+    COMBAT_PLAN_HOOK(combat_unet_up_fused, y, partials, rows_per_group, s, ss, ts, N, H, W, C, eps, mean, rstd, scale, shift, out);
     if (!y || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     if (s && (!ss || !ts)) return COMBAT_EINVAL;
     if (partials ? (rows_per_group <= 0 || rows_per_group > kFusedMaxRows) : (long)H * W > kFusedMaxDirect) return COMBAT_EINVAL;
@@ -932,6 +938,7 @@ extern "C" int combat_unet_up_fused(const void *y, const float *partials, int32_
 extern "C" int combat_unet_up_bwd_fused(const void *d_out, const void *out, const void *y, const float *mean,
                                         const float *rstd, int32_t N, int32_t H, int32_t W, int32_t C, void *du,
                                         void *dx, void *stream) {
+    COMBAT_PLAN_HOOK(combat_unet_up_bwd_fused, d_out, out, y, mean, rstd, N, H, W, C, du, dx);
     if (!d_out || !out || !y || !mean || !rstd || !du || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7))
         return COMBAT_EINVAL;
     if ((long)H * W > kFusedMaxDirect) return COMBAT_EINVAL;
@@ -947,6 +954,7 @@ extern "C" int combat_norm_bwd_fused(const void *dz, const void *x, const void *
                                      int32_t groups, int32_t rows_per_group, int64_t px_per_group, int32_t C,
                                      const float *gamma, const float *mean, const float *rstd, float *dgamma,
                                      float *dbeta, float *scratch, int64_t scratch_bytes, void *dx, void *stream) {
+    COMBAT_PLAN_HOOK(combat_norm_bwd_fused, dz, x, add, partials, groups, rows_per_group, px_per_group, C, gamma, mean, rstd, dgamma, dbeta, scratch, scratch_bytes, dx);
     if (!dz || !x || !dx || !mean || !rstd || groups <= 0 || px_per_group <= 0 || C <= 0 || (C & 7))
         return COMBAT_EINVAL;
     if (partials ? rows_per_group <= 0 : px_per_group > kFusedMaxDirect) return COMBAT_EINVAL;
@@ -972,6 +980,7 @@ extern "C" int combat_norm_bwd_fused(const void *dz, const void *x, const void *
 extern "C" int combat_bn_eval_fold(const float *gamma, const float *beta, const float *running_mean,
                                    const float *running_var, float eps, int32_t C, float *scale, float *shift,
                                    void *stream) {
+    COMBAT_PLAN_HOOK(combat_bn_eval_fold, gamma, beta, running_mean, running_var, eps, C, scale, shift);
     if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return COMBAT_EINVAL;
     hipLaunchKernelGGL(bn_eval_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta,
                        running_mean, running_var, eps, C, scale, shift);
@@ -980,6 +989,7 @@ extern "C" int combat_bn_eval_fold(const float *gamma, const float *beta, const 
 }
 
 extern "C" int combat_bn_eval_fold_batch(const combat_bn_desc *descs, int32_t n, float eps, void *stream) {
+    COMBAT_PLAN_HOOK(combat_bn_eval_fold_batch, descs, n, eps);
     if (!descs || n < 0) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     hipLaunchKernelGGL(bn_eval_fold_batch_kernel, dim3(2, (unsigned)n), dim3(256), 0, as_stream(stream), descs, eps);
@@ -989,6 +999,7 @@ extern "C" int combat_bn_eval_fold_batch(const combat_bn_desc *descs, int32_t n,
 
 extern "C" int combat_group_stats(const void *x, int32_t groups, int32_t rows_per_group, int32_t C,
                                   float *partials, void *stream) {
+    COMBAT_PLAN_HOOK(combat_group_stats, x, groups, rows_per_group, C, partials);
     if (!x || !partials || groups <= 0 || rows_per_group <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     const long t = (long)groups * (C >> 3);
     hipLaunchKernelGGL(group_stats_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, as_stream(stream),
@@ -1001,6 +1012,7 @@ extern "C" int combat_group_stats(const void *x, int32_t groups, int32_t rows_pe
 extern "C" int combat_group_stats_bwd(const void *dz, const void *x, int32_t groups, int32_t rows_per_group,
                                       int32_t C, int32_t parts_per_image, const float *xh_mean,
                                       const float *xh_rstd, float *partials, void *stream) {
+    COMBAT_PLAN_HOOK(combat_group_stats_bwd, dz, x, groups, rows_per_group, C, parts_per_image, xh_mean, xh_rstd, partials);
     if (!dz || !x || !partials || !xh_mean || !xh_rstd || parts_per_image < 0) return COMBAT_EINVAL;
     if (groups <= 0 || rows_per_group <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     const long t = (long)groups * (C >> 3);
@@ -1014,6 +1026,7 @@ extern "C" int combat_group_stats_bwd(const void *dz, const void *x, int32_t gro
 extern "C" int combat_norm_bwd_apply(const void *dz, const void *x, const void *add, void *dx, int64_t rows,
                                      int32_t C, int32_t rows_per_group, int32_t grouped, const float *ca,
                                      const float *cb, const float *cc, void *stream) {
+    COMBAT_PLAN_HOOK(combat_norm_bwd_apply, dz, x, add, dx, rows, C, rows_per_group, grouped, ca, cb, cc);
     if (!dz || !x || !dx || !ca || !cb || !cc || rows <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     if (grouped && rows_per_group <= 0) return COMBAT_EINVAL;
     const long total = rows * (C >> 3);

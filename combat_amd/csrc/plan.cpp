@@ -1,0 +1,118 @@
+// C-side replay of a recorded call sequence ("plan"): the launch list of one network pass is walked here, not in
+// Python -- one foreign call per plan instead of one per kernel, hand-off events created once and reused.
+//
+// The host mirror (combat_amd/engine.py::Plan) builds a plan by arming combat_plan_record(plan, queue) and then making
+// the ordinary C-ABI call with a null stream: the entry point's COMBAT_PLAN_HOOK captures it.  queue < 0: the call
+// runs on the plan's own stream; queue >= 0: it may run beside the calls that follow it (weight gradients), on
+// auxiliary stream `queue`, ordered after everything recorded before it by an event.  combat_plan_run replays a
+// range of calls; combat_plan_join makes the plan's own stream wait for the auxiliary streams it used (at a
+// data-parallel all-reduce mark, and at the end of the plan).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "combat_hip.h"
+#include "plan.hpp"
+
+struct combat_plan {
+    struct Call {
+        std::function<int(void *)> fn;
+        int queue;
+    };
+    std::vector<Call> calls;
+    std::vector<hipEvent_t> handoff;   // one per call that runs on an auxiliary queue
+    std::vector<hipEvent_t> join;      // one per auxiliary queue
+    unsigned used = 0;                 // auxiliary queues with work not yet joined
+    int failed = -1;                   // index of the call whose status combat_plan_run returned
+};
+
+namespace {
+thread_local combat_plan *t_plan = nullptr;
+thread_local int t_queue = -1;
+
+hipEvent_t new_event() {
+    hipEvent_t e = nullptr;
+    return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess ? e : nullptr;
+}
+}  // namespace
+
+namespace combat_plan_detail {
+bool armed() { return t_plan != nullptr; }
+int capture(std::function<int(void *)> call) {
+    combat_plan *p = t_plan;
+    t_plan = nullptr;   // one-shot: a captured call that itself calls entry points replays them normally
+    p->calls.push_back({std::move(call), t_queue});
+    p->handoff.push_back(nullptr);
+    return COMBAT_OK;
+}
+}  // namespace combat_plan_detail
+
+extern "C" combat_plan *combat_plan_create(void) { return new (std::nothrow) combat_plan(); }
+
+extern "C" void combat_plan_destroy(combat_plan *p) {
+    if (!p) return;
+    for (hipEvent_t e : p->handoff)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->join)
+        if (e) (void)hipEventDestroy(e);
+    delete p;
+}
+
+extern "C" int combat_plan_record(combat_plan *p, int32_t queue) {
+    if (!p || t_plan) return COMBAT_EINVAL;
+    t_plan = p;
+    t_queue = queue;
+    return COMBAT_OK;
+}
+
+extern "C" int combat_plan_record_cancel(void) {   // the armed call was not a hooked entry point
+    const bool was = t_plan != nullptr;
+    t_plan = nullptr;
+    return was ? 1 : 0;
+}
+
+extern "C" int32_t combat_plan_size(const combat_plan *p) { return p ? (int32_t)p->calls.size() : COMBAT_EINVAL; }
+
+extern "C" int32_t combat_plan_failed_call(const combat_plan *p) { return p ? p->failed : COMBAT_EINVAL; }
+
+extern "C" int combat_plan_run(combat_plan *p, int32_t begin, int32_t end, void *stream, void *const *aux_streams, int32_t n_aux) {
+    if (!p || begin < 0 || end > (int32_t)p->calls.size() || begin > end || n_aux < 0 || (n_aux && !aux_streams)) return COMBAT_EINVAL;
+    hipStream_t main_st = reinterpret_cast<hipStream_t>(stream);
+    for (int32_t i = begin; i < end; ++i) {
+        const combat_plan::Call &c = p->calls[i];
+        int rc;
+        if (c.queue >= 0 && n_aux > 0) {
+            const int q = c.queue % n_aux;
+            hipStream_t aux = reinterpret_cast<hipStream_t>(aux_streams[q]);
+            hipEvent_t &ev = p->handoff[i];
+            if (!ev && !(ev = new_event())) return COMBAT_ELAUNCH;
+            // everything enqueued so far (the producers of this call's operands) happens-before it
+            if (hipEventRecord(ev, main_st) != hipSuccess || hipStreamWaitEvent(aux, ev, 0) != hipSuccess) return COMBAT_ELAUNCH;
+            rc = c.fn(aux_streams[q]);
+            p->used |= 1u << q;
+        } else {
+            rc = c.fn(stream);
+        }
+        if (rc != COMBAT_OK) {
+            p->failed = i;
+            return rc;
+        }
+    }
+    return COMBAT_OK;
+}
+
+extern "C" int combat_plan_join(combat_plan *p, void *stream, void *const *aux_streams, int32_t n_aux) {
+    if (!p || n_aux < 0 || n_aux > 32 || (n_aux && !aux_streams)) return COMBAT_EINVAL;
+    hipStream_t main_st = reinterpret_cast<hipStream_t>(stream);
+    if ((int32_t)p->join.size() < n_aux) p->join.resize(n_aux, nullptr);
+    for (int q = 0; q < n_aux; ++q) {
+        if (!(p->used & (1u << q))) continue;
+        hipEvent_t &ev = p->join[q];
+        if (!ev && !(ev = new_event())) return COMBAT_ELAUNCH;
+        if (hipEventRecord(ev, reinterpret_cast<hipStream_t>(aux_streams[q])) != hipSuccess ||
+            hipStreamWaitEvent(main_st, ev, 0) != hipSuccess)
+            return COMBAT_ELAUNCH;
+    }
+    p->used = 0;
+    return COMBAT_OK;
+}

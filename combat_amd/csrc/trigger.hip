@@ -9,6 +9,7 @@
 // T.GaussianBlur (:165,:194,:226), MSELoss term (:234), PostTensorTransform (utils/dataloader.py:45-60,
 // kornia), dct_2d(byte()) (train_generator.py:245).
 #include "common.hpp"
+#include "plan.hpp"
 
 namespace {
 
@@ -429,6 +430,7 @@ int set_smem(K kern, int bytes) {
 extern "C" int combat_trigger_fwd(const float *x, const void *noise, const float *P, const float *k1,
                                   float noise_rate, int32_t n, int32_t hw, const int32_t *src_index, float *out,
                                   void *out_c8, float *mse_partial, void *stream) {
+    COMBAT_PLAN_HOOK(combat_trigger_fwd, x, noise, P, k1, noise_rate, n, hw, src_index, out, out_c8, mse_partial);
     if (!x || !noise || !P || !k1 || !out || n < 0 || hw < 16 || hw > 64 || (hw & 3)) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     const int bytes = (4 * hw * hw + 2 * hw) * 4;
@@ -443,6 +445,7 @@ extern "C" int combat_trigger_fwd(const float *x, const void *noise, const float
 extern "C" int combat_trigger_bwd(const float *x, const void *noise, const float *P, const float *k1,
                                   float noise_rate, int32_t n, int32_t hw, const float *d_out, const float *d_out2,
                                   const float *out, float l2_scale, int32_t pre_tanh, void *d_noise, void *stream) {
+    COMBAT_PLAN_HOOK(combat_trigger_bwd, x, noise, P, k1, noise_rate, n, hw, d_out, d_out2, out, l2_scale, pre_tanh, d_noise);
     if (!x || !noise || !P || !k1 || !d_noise || n < 0 || hw < 16 || hw > 64 || (hw & 3)) return COMBAT_EINVAL;
     if (l2_scale != 0.f && !out) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
@@ -457,6 +460,7 @@ extern "C" int combat_trigger_bwd(const float *x, const void *noise, const float
 
 extern "C" int combat_augment_fwd(const float *x, const int32_t *src_index, const float *params, int32_t n,
                                   int32_t hw, void *out_c8, float *out_f32, void *stream) {
+    COMBAT_PLAN_HOOK(combat_augment_fwd, x, src_index, params, n, hw, out_c8, out_f32);
     if (!x || !out_c8 || n < 0 || hw < 2 || hw > 1024) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     if (hw > 96) {
@@ -475,6 +479,7 @@ extern "C" int combat_augment_fwd(const float *x, const int32_t *src_index, cons
 
 extern "C" int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const float *params, int32_t n, int32_t hw,
                                   float *d_x, int32_t accumulate, void *stream) {
+    COMBAT_PLAN_HOOK(combat_augment_bwd, d_c8, c8_channels, params, n, hw, d_x, accumulate);
     if (!d_c8 || !d_x || c8_channels < 3 || n < 0 || hw < 2 || hw > 1024) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     if (hw > 96) {
@@ -494,6 +499,7 @@ extern "C" int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const f
 }
 
 extern "C" int combat_dct_u8(const float *x, const float *D, int32_t n, int32_t hw, void *out_c8, void *stream) {
+    COMBAT_PLAN_HOOK(combat_dct_u8, x, D, n, hw, out_c8);
     if (!x || !D || !out_c8 || n < 0 || hw < 4 || hw > 256 || (hw & 3) || (hw > 64 && (hw & 15))) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     if (hw > 64) {

@@ -13,6 +13,7 @@
 //                          gradients of fc2.weight, fc2.bias, fc1.bias (fc1.weight and the encoder receive exactly 0)
 // Everything here is latency-bound glue around 8 numbers; the images are fp32 [N][3][H][H] planes as in trigger.hip.
 #include "common.hpp"
+#include "plan.hpp"
 
 namespace {
 
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256) void wanet_field_bwd_kernel(const FieldBwdArgs
 
 extern "C" int combat_grid_head_fwd(const float *fc1_bias, const float *fc2_weight, const float *fc2_bias, int32_t nf,
                                     int32_t nout, float *field, void *stream) {
+    COMBAT_PLAN_HOOK(combat_grid_head_fwd, fc1_bias, fc2_weight, fc2_bias, nf, nout, field);
     if (!fc1_bias || !fc2_weight || !fc2_bias || !field || nf <= 0 || nf > kMaxNf || nout <= 0 || nout > kMaxField) return COMBAT_EINVAL;
     hipLaunchKernelGGL(grid_head_fwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), fc1_bias, fc2_weight, fc2_bias, nf, nout, field);
     CB_LAUNCH_CHECK();
@@ -217,6 +219,7 @@ extern "C" int combat_grid_head_fwd(const float *fc1_bias, const float *fc2_weig
 
 extern "C" int combat_wanet_grid(const float *field, const float *U, int32_t S, int32_t H, float rescale, float *noise_grid,
                                  float *grid, void *stream) {
+    COMBAT_PLAN_HOOK(combat_wanet_grid, field, U, S, H, rescale, noise_grid, grid);
     if (!field || !U || !noise_grid || !grid || S < 1 || 2 * S * S > kMaxField || H < 2) return COMBAT_EINVAL;
     hipLaunchKernelGGL(wanet_grid_kernel, dim3((H * H + 255) / 256), dim3(256), 0, as_stream(stream), field, U, S, H, rescale,
                        noise_grid, grid);
@@ -226,6 +229,7 @@ extern "C" int combat_wanet_grid(const float *field, const float *U, int32_t S, 
 
 extern "C" int combat_warp_fwd(const float *x, const int32_t *src_index, const float *grid, int32_t per_image_grid, int32_t n,
                                int32_t H, float *out, void *stream) {
+    COMBAT_PLAN_HOOK(combat_warp_fwd, x, src_index, grid, per_image_grid, n, H, out);
     if (!x || !grid || !out || n < 0 || H < 2) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     hipLaunchKernelGGL(warp_fwd_kernel, dim3((H * H + 255) / 256, n), dim3(256), 0, as_stream(stream), x, src_index, grid,
@@ -236,6 +240,7 @@ extern "C" int combat_warp_fwd(const float *x, const int32_t *src_index, const f
 
 extern "C" int combat_warp_bwd(const float *x, const float *d_out, const float *d_out2, const float *grid,
                                int32_t per_image_grid, int32_t n, int32_t H, int32_t groups, float *partial, void *stream) {
+    COMBAT_PLAN_HOOK(combat_warp_bwd, x, d_out, d_out2, grid, per_image_grid, n, H, groups, partial);
     if (!x || !d_out || !grid || !partial || n <= 0 || H < 2 || groups < 1) return COMBAT_EINVAL;
     const int per = (n + groups - 1) / groups;
     hipLaunchKernelGGL(warp_bwd_kernel, dim3((H * H + 255) / 256, groups), dim3(256), 0, as_stream(stream), x, d_out, d_out2, grid,
@@ -246,6 +251,7 @@ extern "C" int combat_warp_bwd(const float *x, const float *d_out, const float *
 
 extern "C" int combat_warp_bwd_input(const float *d_out, const float *grid, int32_t per_image_grid, int32_t n, int32_t H,
                                      float *d_x, void *stream) {
+    COMBAT_PLAN_HOOK(combat_warp_bwd_input, d_out, grid, per_image_grid, n, H, d_x);
     if (!d_out || !grid || !d_x || n < 0 || H < 2) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     hipStream_t st = as_stream(stream);
@@ -260,6 +266,7 @@ extern "C" int combat_wanet_field_bwd(const float *partial, int32_t groups, cons
                                       int32_t H, float rescale, float l2_scale, const float *field, const float *fc1_bias,
                                       const float *fc2_weight, int32_t nf, float *d_fc1_bias, float *d_fc2_weight,
                                       float *d_fc2_bias, float *d_field, void *stream) {
+    COMBAT_PLAN_HOOK(combat_wanet_field_bwd, partial, groups, noise_grid, U, S, H, rescale, l2_scale, field, fc1_bias, fc2_weight, nf, d_fc1_bias, d_fc2_weight, d_fc2_bias, d_field);
     if (!partial || !noise_grid || !U || !field || !fc1_bias || !fc2_weight || !d_fc1_bias || !d_fc2_weight || !d_fc2_bias)
         return COMBAT_EINVAL;
     if (S < 1 || 2 * S * S > kMaxField || H < 2 || groups < 1 || nf <= 0 || nf > kMaxNf) return COMBAT_EINVAL;

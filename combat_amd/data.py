@@ -63,21 +63,49 @@ def _load_imagenet10(root: str, train: bool, hw: int) -> Tuple[np.ndarray, np.nd
     """ImageNet-10 as the reference uses it (utils/dataloader.py:83-95: torchvision.datasets.ImageNet under
     <data_root>/imagenet10, split train / val, resized to 224 x 224 by get_transform :27), from a pre-decoded cache
     `imagenet10_{train,val}_224.npz` with uint8 `images` [N,224,224,3] (or [N,3,224,224]) and int `labels` [N] (0..9).
-    JPEG decoding is outside this package, as for CelebA; the file is memory-mapped when stored uncompressed."""
+    JPEG decoding is outside this package, as for CelebA.  (np.load ignores mmap_mode for .npz archives: the array is
+    read once, and only copied again if it is stored NHWC.)"""
     path = os.path.join(root, "imagenet10_%s_%d.npz" % ("train" if train else "val", hw))
     if not os.path.exists(path):
         raise FileNotFoundError("ImageNet-10 cache %r not found (uint8 images [N,%d,%d,3] + labels [N]); nothing is "
                                 "downloaded.  --synthetic runs the same shapes on generated data." % (path, hw, hw))
-    z = np.load(path, mmap_mode="r")
+    z = np.load(path)
     img = z["images"]
     if img.shape[-1] == 3:
-        img = img.transpose(0, 3, 1, 2)
-    return np.ascontiguousarray(img), np.asarray(z["labels"]).astype(np.int64)
+        img = np.ascontiguousarray(img.transpose(0, 3, 1, 2))
+    return img, np.asarray(z["labels"]).astype(np.int64)
 
 
 def synthetic_cifar10(n: int, seed: int, hw: int = 32, classes: int = 10) -> Tuple[np.ndarray, np.ndarray]:
     g = np.random.default_rng(seed)
     return g.integers(0, 256, (n, 3, hw, hw), dtype=np.uint8), g.integers(0, classes, n).astype(np.int64)
+
+
+def synthetic_structured(n: int, seed: int, hw: int = 32, classes: int = 10, proto_seed: int = 2024,
+                         signal: float = 0.07, clutter: float = 0.2, grain: float = 0.08) -> Tuple[np.ndarray, np.ndarray]:
+    """A LEARNABLE CIFAR-shaped set for end-metric checks (clean accuracy / attack success rate need something to
+    learn; uniform noise with random labels has nothing): class c has a fixed smooth prototype field (a 3 x 8 x 8
+    Gaussian draw upsampled bilinearly to hw x hw, the same for every split: `proto_seed`), an image is
+    0.5 + signal * prototype[label] + clutter-weighted smooth field of its own + grain-weighted white noise, clipped
+    and quantised to uint8 like a stored dataset.  Everything comes from numpy's PCG64 streams (`default_rng`),
+    which are specified bit for bit, so the build container (reference modules, tests/golden/make_golden.py) and
+    the GPU box generate identical bytes from (n, seed)."""
+    def smooth(g, count):
+        z = g.standard_normal((count, 3, 8, 8)).astype(np.float32)
+        # separable bilinear upsampling 8 -> hw (align_corners=False), written out so that no library kernel decides a bit
+        pos = (np.arange(hw, dtype=np.float32) + 0.5) * (8.0 / hw) - 0.5
+        i0 = np.clip(np.floor(pos), 0, 7).astype(np.int64)
+        i1 = np.clip(i0 + 1, 0, 7)
+        w1 = np.clip(pos - i0, 0.0, 1.0).astype(np.float32)
+        zr = z[:, :, i0, :] * (1 - w1)[None, None, :, None] + z[:, :, i1, :] * w1[None, None, :, None]
+        return zr[:, :, :, i0] * (1 - w1)[None, None, None, :] + zr[:, :, :, i1] * w1[None, None, None, :]
+
+    protos = smooth(np.random.default_rng(proto_seed), classes)
+    g = np.random.default_rng(seed)
+    labels = g.integers(0, classes, n).astype(np.int64)
+    img = np.float32(0.5) + np.float32(signal) * protos[labels] + np.float32(clutter) * smooth(g, n) \
+        + np.float32(grain) * g.standard_normal((n, 3, hw, hw)).astype(np.float32)
+    return np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8), labels
 
 
 class ArrayLoader:
@@ -200,7 +228,10 @@ def get_dataloader(opt, train: bool = True, pretensor_transform: bool = False, b
         raise Exception("Invalid Dataset")
     if getattr(opt, "synthetic", False):
         n = getattr(opt, "synthetic_size", 0) or (CIFAR_TRAIN if train else CIFAR_TEST)
-        x, y = synthetic_cifar10(n, 1234 if train else 4321, opt.input_height, opt.num_classes)
+        if not getattr(opt, "synthetic_size", 0):      # keep the default split under ~2 GB of uint8 whatever the image size
+            n = max(bs, min(n, (2 << 30) // (3 * opt.input_height * opt.input_height)))
+        gen = synthetic_structured if getattr(opt, "synthetic_kind", "noise") == "structured" else synthetic_cifar10
+        x, y = gen(n, 1234 if train else 4321, opt.input_height, opt.num_classes)
     elif opt.dataset == "celeba":
         x, y = _load_celeba(opt.data_root, train, opt.input_height)
     elif opt.dataset == "imagenet10":

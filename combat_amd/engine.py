@@ -47,11 +47,14 @@ class Plan:
         #                                   ms/step, 2 for the surrogate's 4.14 -> 4.17: one queue it stays
         self.wgrads: List[Tuple] = []     # (call index, WgradArgs) of the weight-gradient launches
         self._ws = None
+        self._cplan = None                # combat_plan* of the compiled form (built on first run)
+        self._prog = None
 
     def add(self, what: str, cfunc, *args, aux: bool = False) -> None:
         """aux: the call's result is only consumed after the plan (weight gradients: by the optimiser /
         all-reduce), so it may run on the auxiliary stream beside the calls that follow it."""
         self.calls.append((cfunc, args, what))
+        self._prog = None
         if aux:
             self.aux[len(self.calls) - 1] = self.next_aux_queue()
 
@@ -69,6 +72,7 @@ class Plan:
         (f0, a0, w0), (f1, a1, w1) = self.calls[i], self.calls[i + 1]
         assert f0 is lib.combat_conv_gemm and f1 is lib.combat_conv_gemm and not self.marks and not self.aux
         self.calls[i:i + 2] = [(lib.combat_conv_gemm_pair, (a0[0], a1[0]), w0 + "+" + w1)]
+        self._prog = None
 
     def workspace(self, device) -> torch.Tensor:
         """Scratch of this plan's convolutions (split reductions of skinny layers).  Per plan: the calls of
@@ -81,8 +85,104 @@ class Plan:
         """Every gradient at flat offset >= grad_offset is final once the calls recorded so far ran."""
         self.marks[len(self.calls) - 1] = grad_offset
 
+    compiled = os.environ.get("COMBAT_PLAN_PY", "0") != "1"   # False: replay every plan from Python (debugging / A-B timing)
+
+    def _program(self):
+        """The C-side form of this plan (csrc/plan.cpp), built on first use: every C-ABI call is captured into a
+        combat_plan with its queue; Python callables (the gradient-zeroing hand-off) and the all-reduce marks split
+        it into ranges.  Returns [("c", begin, end) | ("py", func, args, what) | ("mark", offset)]."""
+        if self._prog is not None:
+            return self._prog
+        if self._cplan:
+            lib.combat_plan_destroy(self._cplan)
+        cp = self._cplan = lib.combat_plan_create()
+        if not cp:
+            raise CombatHipError("combat_plan_create failed")
+        prog, names, begin = [], [], None
+        for ci, (cfunc, args, what) in enumerate(self.calls):
+            captured = False
+            if getattr(cfunc, "argtypes", None) is not None:       # a ctypes entry point
+                ops.check(lib.combat_plan_record(cp, self.aux.get(ci, -1)), "combat_plan_record")
+                try:
+                    rc = cfunc(*args, None)
+                finally:
+                    captured = not lib.combat_plan_record_cancel()
+                if captured and rc:
+                    raise CombatHipError("%s/%s: recording failed (%d)" % (self.name, what, rc))
+            if captured:
+                names.append(what)
+                if begin is None:
+                    begin = len(names) - 1
+            else:
+                if begin is not None:
+                    prog.append(("c", begin, len(names)))
+                    begin = None
+                assert ci not in self.aux, "only C-ABI calls can run on an auxiliary queue"
+                prog.append(("py", cfunc, args, what))
+            if ci in self.marks:
+                if begin is not None:
+                    prog.append(("c", begin, len(names)))
+                    begin = None
+                prog.append(("mark", self.marks[ci]))
+        if begin is not None:
+            prog.append(("c", begin, len(names)))
+        assert lib.combat_plan_size(cp) == len(names)
+        # without an all-reduce callback the marks are no-ops: neighbouring C ranges become one foreign call
+        merged = []
+        for it in prog:
+            if it[0] == "mark":
+                continue
+            if it[0] == "c" and merged and merged[-1][0] == "c" and merged[-1][2] == it[1]:
+                merged[-1] = ("c", merged[-1][1], it[2])
+            else:
+                merged.append(it)
+        self._prog, self._prog_nomark, self._cnames = prog, merged, names
+        return prog
+
     def run(self, prof: Optional[list] = None, on_mark=None) -> None:
-        """Replay.  `prof` (a list) switches on per-launch HIP-event bracketing of the convolution and
+        """Replay.  The launch list is walked in C (combat_plan_run: one foreign call per plan, or per range between
+        two all-reduce marks / Python hand-offs), with the auxiliary-queue hand-off events created once per plan.
+        `prof` (a list) selects the Python replay with per-launch HIP-event bracketing instead (`_run_py`).
+        `on_mark(offset)` is called right after the call that completes the gradients above `offset`
+        has been enqueued (data-parallel bucketed all-reduce overlapping the rest of the backward)."""
+        if prof is not None or not Plan.compiled:
+            return self._run_py(prof, on_mark)
+        prog = self._program()
+        if on_mark is None:
+            prog = self._prog_nomark
+        stream = torch.cuda.current_stream()
+        st = stream.cuda_stream
+        n_aux = self.aux_queues if (self.aux and not Plan.serial) else 0
+        auxp = _aux_pointers(stream, n_aux) if n_aux else None
+        cp = self._cplan
+        for it in prog:
+            kind = it[0]
+            if kind == "c":
+                rc = lib.combat_plan_run(cp, it[1], it[2], st, auxp, n_aux)
+                if rc:
+                    what = self._cnames[lib.combat_plan_failed_call(cp)]
+                    kindname = {-1: "invalid shape/argument", -2: "HIP launch failed"}.get(rc, "status %d" % rc)
+                    raise CombatHipError("%s/%s: %s" % (self.name, what, kindname))
+            elif kind == "py":
+                rc = it[1](*it[2], st)
+                if rc:
+                    raise CombatHipError("%s/%s: status %d" % (self.name, it[3], rc))
+            else:
+                if n_aux:   # the gradients above the mark include auxiliary-stream results
+                    ops.check(lib.combat_plan_join(cp, st, auxp, n_aux), "combat_plan_join")
+                on_mark(it[1])
+        if n_aux:           # join: whoever runs after the plan sees every result
+            ops.check(lib.combat_plan_join(cp, st, auxp, n_aux), "combat_plan_join")
+
+    def __del__(self):
+        try:
+            if self._cplan:
+                lib.combat_plan_destroy(self._cplan)
+        except Exception:
+            pass
+
+    def _run_py(self, prof: Optional[list] = None, on_mark=None) -> None:
+        """Replay from Python, one foreign call per launch (the instrumented form).  `prof` (a list) switches on per-launch HIP-event bracketing of the convolution and
         weight-gradient launches on the launch stream: it receives (plan/what, ConvArgs | WgradArgs,
         start_event, end_event).
         `on_mark(offset)` is called right after the call that completes the gradients above `offset`
@@ -137,6 +237,17 @@ class Plan:
 
 
 _AUX_STREAMS: Dict = {}
+_AUX_POINTERS: Dict = {}
+
+
+def _aux_pointers(parent: torch.cuda.Stream, n: int):
+    """void*[n] of the parent stream's auxiliary streams, for combat_plan_run (built once per parent stream)."""
+    key = (parent.device, parent.cuda_stream, n)
+    arr = _AUX_POINTERS.get(key)
+    if arr is None:
+        arr = (ctypes.c_void_p * n)(*[_aux_stream(parent, k).cuda_stream for k in range(n)])
+        _AUX_POINTERS[key] = arr
+    return arr
 
 
 def _aux_stream(parent: torch.cuda.Stream, k: int = 0) -> torch.cuda.Stream:
@@ -327,6 +438,7 @@ def balance_wgrads(plan: Plan, device) -> None:
         return
     aux_calls = [(ci, a) for ci, a in plan.wgrads if ci in plan.aux]
     ws = _wgrad_workspace(device, -1)
+    plan._prog = None
     for ci, a in aux_calls[-tail:]:
         plan.aux.pop(ci, None)
         a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
@@ -1312,6 +1424,16 @@ class GridEngine(NetEngine):
         ops.check(lib.combat_wanet_grid(self.field.data_ptr(), g["U"].data_ptr(), self.S, hw, float(rescale),
                                         g["noise_grid"].data_ptr(), g["grid"].data_ptr(), st), "combat_wanet_grid")
         return g
+
+    def head_grad_range(self) -> Tuple[int, int]:
+        """[lo, hi) of the flat gradient buffer that holds every gradient this engine ever writes (fc1.bias,
+        fc2.weight, fc2.bias are consecutive parameters); the rest of fp.grad stays exactly zero."""
+        offs = [self.fp.offsets[k] for k in ("fc1.bias", "fc2.weight", "fc2.bias")]
+        lo = min(o for o, _, _ in offs)
+        hi = max(o + n for o, n, _ in offs)
+        inside = sum(n for o, n, _ in self.fp.offsets.values() if lo <= o < hi)
+        assert inside == sum(n for _, n, _ in offs), "head parameters are not contiguous in the flat buffer"
+        return lo, hi
 
     def backward_field(self, partial: torch.Tensor, groups: int, hw: int, rescale: float, l2_scale: float, st=None) -> None:
         """d(loss)/d(grid) partial sums -> gradients of the head in fp.grad (the rest of fp.grad must be zero)."""

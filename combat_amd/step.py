@@ -115,6 +115,32 @@ def shared_stream(device, kind: str, priority: int = 0) -> torch.cuda.Stream:
     return s
 
 
+def backward_allreduce(plan, eng, pg, world: int, reducers: dict, prof=None) -> None:
+    """Run a backward plan; with several ranks, all-reduce the flat gradient buffer in buckets, each launched as
+    soon as the plan has enqueued the kernels that complete it (`Plan.mark`), so that the first buckets travel
+    while the rest of the backward still runs.  `reducers` caches the GradReducer per plan."""
+    if world == 1:
+        plan.run(prof)
+        return
+    red = reducers.get(id(plan))
+    if red is None:
+        ranges = bucket_ranges(eng.fp.total, plan.marks.values())
+        red = (GradReducer(eng.fp.grad, ranges, pg), ranges)
+        reducers[id(plan)] = red
+    reducer, ranges = red
+    launched = set()
+
+    def on_mark(offset):
+        for i, (lo, hi) in enumerate(ranges):
+            if lo >= offset and i not in launched:
+                launched.add(i)
+                reducer.launch(i)
+
+    plan.run(prof, on_mark=on_mark)
+    on_mark(0)
+    reducer.wait()
+
+
 class AlternatedStep:
     """Owns the engines, slots and small device tables of one rank's step."""
 
@@ -437,28 +463,7 @@ class AlternatedStep:
             F.mse_loss(e[:, :, :, 1:] - e[:, :, :, :-1], eb[:, :, :, 1:] - eb[:, :, :, :-1])
 
     def _backward_allreduce(self, plan, eng, prof) -> None:
-        """Run a backward plan; with several ranks, all-reduce the flat gradient buffer in buckets,
-        each launched as soon as the plan has enqueued the kernels that complete it."""
-        if self.world == 1:
-            plan.run(prof)
-            return
-        red = self._reducers.get(id(plan))
-        if red is None:
-            ranges = bucket_ranges(eng.fp.total, plan.marks.values())
-            red = (GradReducer(eng.fp.grad, ranges, self.pg), ranges)
-            self._reducers[id(plan)] = red
-        reducer, ranges = red
-        launched = set()
-
-        def on_mark(offset):
-            for i, (lo, hi) in enumerate(ranges):
-                if lo >= offset and i not in launched:
-                    launched.add(i)
-                    reducer.launch(i)
-
-        plan.run(prof, on_mark=on_mark)
-        on_mark(0)
-        reducer.wait()
+        backward_allreduce(plan, eng, self.pg, self.world, self._reducers, prof)
 
     # ------------------------------------------------------------------ metrics
     def _slot_sets(self):
@@ -561,7 +566,10 @@ class WanetStep(AlternatedStep):
                                       self.WARP_GROUPS, self._wpartial.data_ptr(), st), "warp bwd")
         eG.backward_field(self._wpartial, self.WARP_GROUPS, self.hw, float(self.opt.grid_rescale), float(self.opt.L2_weight), st)
         if self.world > 1:
-            torch.distributed.all_reduce(eG.fp.grad, group=self.pg)
+            # only fc1.bias, fc2.weight and fc2.bias ever receive a gradient (GridEngine): one contiguous range of
+            # ~640 floats travels, not the 19-MB flat buffer whose remainder is exactly zero on every rank
+            lo, hi = eG.head_grad_range()
+            torch.distributed.all_reduce(eG.fp.grad[lo:hi], group=self.pg)
 
 
 def _zero_grad(fp, st):
@@ -578,7 +586,11 @@ class ClassifierStep:
         self.opt, self.netC, self.netG = opt, netC, netG
         self.dev = next(netC.parameters()).device
         self.eC: PreActEngine = netC._net_engine()
-        self.eG: Optional[UnetEngine] = netG._net_engine() if netG is not None else None
+        self.eG = netG._net_engine() if netG is not None else None      # UnetEngine, or GridEngine (WaNet)
+        # train_victim_wanet.py:85-96: the frozen GridGenerator's field warps the poisoned images (no low-pass, no blur)
+        self.wanet = netG is not None and getattr(netG, "arch", "") == "gridgen"
+        if netG is not None and getattr(netG, "arch", "") not in ("unet", "gridgen"):
+            raise ValueError("ClassifierStep: unsupported generator %r (UnetGenerator or GridGenerator expected)" % type(netG).__name__)
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.hw = opt.input_height
@@ -588,7 +600,7 @@ class ClassifierStep:
         self.N = 0
         self._sets: Dict[int, dict] = {}
         self._small: Dict[int, tuple] = {}
-        self._reducer = None
+        self._reducers: Dict = {}
 
     _PER_N = ("cat_src", "tab_i", "tab_f", "slot", "fwd", "bwd")
 
@@ -635,6 +647,7 @@ class ClassifierStep:
         if nb:
             idx[1, :nb] = torch.arange(n, n + nb, dtype=torch.int32)
         self.tab_i.copy_(idx)
+        self.last_poisoned = (trg, nb)     # (image logging: train_victim_wanet.py:127-133)
         aug = self.transforms.sample(n)
         if aug is not None:
             self.tab_f.copy_(torch.from_numpy(aug))
@@ -642,7 +655,11 @@ class ClassifierStep:
         h = self.eC.head_bufs(self.slot)
         h["targets"].copy_(tot)
         self.eC.refresh()
-        if nb:
+        if nb and self.wanet:
+            g = self.eG.forward_grid(hw, float(opt.grid_rescale), st)
+            ops.check(lib.combat_warp_fwd(self.cat_src.data_ptr(), self.tab_i[0].data_ptr(), g["grid"].data_ptr(), 0, nb, hw,
+                                          self.cat_src[n:].data_ptr(), st), "warp")
+        elif nb:
             self.eG.refresh()
             nbk = min(bucket(nb), n)
             if nbk not in self._small:
@@ -661,11 +678,18 @@ class ClassifierStep:
                                          self.tab_f.data_ptr() if aug is not None else None, n, hw,
                                          self.eC.input(self.slot).data_ptr(), None, st), "augment")
         self.fwd.run()
-        self.bwd.run()
-        if self.world > 1:
-            torch.distributed.all_reduce(self.eC.fp.grad, group=self.pg)
+        backward_allreduce(self.bwd, self.eC, self.pg, self.world, self._reducers)   # buckets overlap the backward
         self.eC.fp.sgd_step(float(lr if lr is not None else opt.lr_C), grad_scale=1.0 / self.world)
         self.eC.mark_weights_dirty()
+
+    def poisoned_pair(self):
+        """(inputs_toChange, inputs_bd) of the last batch -- the two tensors the reference's debugging image stacks
+        (train_victim_wanet.py:129) -- or None if that batch had no poisoned image."""
+        trg, nb = getattr(self, "last_poisoned", (None, 0))
+        if not nb:
+            return None
+        n = self.N
+        return self.cat_src[:n][trg.to(self.dev)].clone(), self.cat_src[n:n + nb].clone()
 
     def _slots(self):
         out = [self.slot] if self.N else []

@@ -72,6 +72,7 @@ _FLAGS = [
 _EXTRA = [
     ("--synthetic", dict(action="store_true", help="CIFAR-10-shaped random data instead of --data_root")),
     ("--synthetic_size", dict(type=int, default=0, help="images per synthetic split (0 = dataset size)")),
+    ("--synthetic_kind", dict(type=str, default="noise", help="noise: uniform bytes, random labels; structured: a learnable class-prototype set")),
     ("--max_steps", dict(type=int, default=0, help="stop each epoch after this many batches (0 = all)")),
     ("--log_interval", dict(type=int, default=20, help="batches between progress-bar refreshes (each one syncs)")),
     ("--seed", dict(type=int, default=None, help="seed torch / numpy / random (the reference never seeds)")),

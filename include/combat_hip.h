@@ -129,6 +129,7 @@ typedef struct combat_conv_args {
 #define COMBAT_TILE_G128x32 13
 #define COMBAT_TILE_D256x64 14   /* conv3x3_dma with 256-pixel tiles (eight waves): large layers */
 #define COMBAT_TILE_C8 15        /* 3x3 over C = 8 (c8 images, 3-channel gradients): operands straight into the MFMA registers */
+#define COMBAT_TILE_S128x64 17   /* conv3x3 for C = K = 64, weight-stationary + persistent: the filter bank stays in LDS, 128-pixel tiles (statistics rows as D128x64) */
 #define COMBAT_TILE_D256W64 16   /* conv3x3_dma, 256-pixel tiles as four waves of 64 pixels x 64 channels (16-wide maps, >= 16 rows) */
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);
@@ -452,6 +453,31 @@ int combat_wanet_field_bwd(const float *partial, int32_t groups, const float *no
                            float rescale, float l2_scale, const float *field, const float *fc1_bias, const float *fc2_weight,
                            int32_t nf, float *d_fc1_bias, float *d_fc2_weight, float *d_fc2_bias, float *d_field,
                            void *stream);
+
+/* ---- Plan replay -------------------------------------------------------------------------------------
+ * The reference executes its step as a Python loop over ATen operators (train_generator.py:170-290, one host call
+ * per operator).  Here a network pass is a fixed sequence of the entry points above; a combat_plan holds such a
+ * sequence with its arguments and replays it from C: one foreign call per pass, hand-off events created once.
+ *
+ * Recording: combat_plan_record(plan, queue) arms the calling thread; the NEXT stream-taking entry point it calls
+ * is captured (arguments by value, pointers as pointers: structs such as combat_conv_args must outlive the plan and
+ * may be edited between replays) instead of launched, and returns COMBAT_OK.  queue < 0: replayed on the plan's own
+ * stream; queue >= 0: replayed on auxiliary stream (queue % n_aux), ordered after every call recorded before it,
+ * concurrent with the calls after it (weight gradients beside the input-gradient chain).
+ * combat_plan_run replays calls [begin, end) and returns the first non-zero status (combat_plan_failed_call tells
+ * which call); combat_plan_join orders `stream` after the auxiliary work issued so far (before a gradient
+ * all-reduce, and at the end of a plan).  n_aux == 0 replays everything in line on `stream`.
+ * Threading: one thread records / replays a given plan at a time (the single launching thread per rank that every
+ * entry point of this library assumes: kernel-argument scratch and attribute flags are per process, not per thread). */
+typedef struct combat_plan combat_plan;
+combat_plan *combat_plan_create(void);
+void combat_plan_destroy(combat_plan *plan);
+int combat_plan_record(combat_plan *plan, int32_t queue);
+int combat_plan_record_cancel(void);   /* disarm (the call made was not a capturable entry point); 1 if it was armed */
+int32_t combat_plan_size(const combat_plan *plan);
+int combat_plan_run(combat_plan *plan, int32_t begin, int32_t end, void *stream, void *const *aux_streams, int32_t n_aux);
+int combat_plan_join(combat_plan *plan, void *stream, void *const *aux_streams, int32_t n_aux);
+int32_t combat_plan_failed_call(const combat_plan *plan);
 
 #ifdef __cplusplus
 }

@@ -576,6 +576,235 @@ def golden_eval_victim():
     save("eval_victim.npz", out)
 
 
+# --------------------------------------------------------------------------------------
+# End-metric golden: the whole pipeline (clean classifier -> alternated training -> victim -> eval.py) through the
+# reference modules on a learnable synthetic set, every random draw recorded
+# --------------------------------------------------------------------------------------
+
+
+def _to_float(u8):
+    return (torch.from_numpy(u8).float() / 255 - 0.5) / 0.5        # ToTensor + Normalize(0.5, 0.5) (utils/dataloader.py:35-39)
+
+
+END_CFG = dict(n_train=2048, n_test=1024, bs=128, epochs_a=4, epochs_b=6, epochs_c=6, lr=1e-2, noise_rate=0.08, signal=0.07,
+               seed_train=1234, seed_test=4321, seeds=dict(clean=11, netc=12, netg=13, victim=14), draw_seed=777)
+
+
+def golden_end_metric(name="end_metric.npz", threads=8, cfg=None):
+    """clean-acc / Bd BA / Bd ASR of the reference pipeline (README.md:29-75) on the class-structured synthetic set
+    of combat_amd.data.synthetic_structured -- the same bytes on both sides -- driven through the reference's
+    nn.Modules with torch.optim.SGD in the order of the reference scripts, --post_transform_option no_use (kornia
+    is absent), Gaussian blur restated (torchvision is absent):
+      A  train_clean_classifier.py:75-121 train, :123-160 eval + keep-best           -> clean_model
+      B  train_generator.py:170-290 train, :321-465 eval + keep-best (:433)          -> netG (+ surrogate netC)
+      C  train_victim.py:93-165 train (D3 intent), :168-231 eval + keep-best         -> victim netC
+      D  eval.py:108-152                                                              -> clean acc, Bd BA, Bd ASR
+    Every random draw is recorded (epoch permutations, num_bd, blur sigmas of training and of every evaluation
+    batch, the poisoned index set), so the GPU test replays the repo's own train()/eval() functions on them."""
+    root = os.path.dirname(os.path.dirname(HERE))
+    if root not in sys.path:
+        sys.path.append(root)       # (behind the reference: `config`, `utils` ... must keep resolving to /root/reference)
+    from combat_amd.data import synthetic_structured
+    cfg = dict(END_CFG, **(cfg or {}))
+    torch.set_num_threads(threads)
+    out = {"cfg/" + k: np.int64(v) for k, v in cfg.items() if isinstance(v, int)}
+    out["cfg/lr"], out["cfg/noise_rate"], out["cfg/signal"] = np.float64(cfg["lr"]), np.float64(cfg["noise_rate"]), np.float64(cfg["signal"])
+    out["cfg/seeds"] = np.array([cfg["seeds"][k] for k in ("clean", "netc", "netg", "victim")])
+    xtr_u8, ytr = synthetic_structured(cfg["n_train"], cfg["seed_train"], signal=cfg["signal"])
+    xte_u8, yte = synthetic_structured(cfg["n_test"], cfg["seed_test"], signal=cfg["signal"])
+    out["data/train_sum"], out["data/test_sum"] = np.int64(xtr_u8.astype(np.int64).sum()), np.int64(xte_u8.astype(np.int64).sum())
+    xtr, xte = _to_float(xtr_u8), _to_float(xte_u8)
+    ytr, yte = torch.from_numpy(ytr), torch.from_numpy(yte)
+    bs, n = cfg["bs"], cfg["n_train"]
+    g = np.random.default_rng(cfg["draw_seed"])
+    ce = torch.nn.CrossEntropyLoss()
+    sgd = lambda net: torch.optim.SGD(net.parameters(), cfg["lr"], momentum=0.9, weight_decay=5e-4, nesterov=True)
+    test_batches = [(xte[i:i + bs], yte[i:i + bs]) for i in range(0, cfg["n_test"], bs)]
+    import copy
+    import time
+    t0 = time.time()
+
+    def backdoor(netg, x, sigma):
+        return _blur(torch.clamp(x + _low_freq(netg(x)) * cfg["noise_rate"], -1, 1), sigma)
+
+    # ---- A: clean classifier
+    torch.manual_seed(cfg["seeds"]["clean"])
+    clean = PreActResNet18()
+    opt_a = sgd(clean)
+    perms_a, acc_a, best, best_state = [], [], -1.0, None
+    for ep in range(cfg["epochs_a"]):
+        perm = g.permutation(n)
+        perms_a.append(perm)
+        clean.train()
+        for i in range(0, n, bs):
+            idx = torch.from_numpy(perm[i:i + bs])
+            opt_a.zero_grad()
+            ce(clean(xtr[idx]), ytr[idx]).backward()
+            opt_a.step()
+        clean.eval()
+        with torch.no_grad():
+            c = sum(int((clean(x).argmax(1) == t).sum()) for x, t in test_batches)
+        acc_a.append(c)
+        if c > best:
+            best, best_state = c, copy.deepcopy(clean.state_dict())
+        print("  A epoch %d: clean correct %d / %d  (%.0f s)" % (ep, c, cfg["n_test"], time.time() - t0), flush=True)
+    out["A/perm"], out["A/correct"] = np.stack(perms_a), np.array(acc_a)
+    clean.load_state_dict(best_state)
+    clean.eval()
+    summarize(clean.state_dict().items(), out, "A/final")
+
+    # ---- B: alternated training
+    torch.manual_seed(cfg["seeds"]["netc"])
+    netc = PreActResNet18()
+    torch.manual_seed(cfg["seeds"]["netg"])
+    netg = UnetGenerator(Opt())
+    opt_c, opt_g = sgd(netc), sgd(netg)
+    perms_b, nbs, sc, sg, ev_sig = [], [], [], [], []
+    keys_b = ("clean", "bd", "cm", "cm_ba", "cm_asr", "bd_n")
+    ev_b = {k: [] for k in keys_b}
+    best_c, best_b, best_g = -1.0, -1.0, None
+    for ep in range(cfg["epochs_b"]):
+        perm = g.permutation(n)
+        perms_b.append(perm)
+        for i in range(0, n, bs):
+            idx = torch.from_numpy(perm[i:i + bs])
+            inputs, targets = xtr[idx], ytr[idx]
+            bd_targets = torch.zeros_like(targets)
+            trg = (targets == bd_targets).nonzero()[:, 0]
+            ntrg = (targets != bd_targets).nonzero()[:, 0]
+            nb = int(np.sum(g.random(len(trg)) < 0.5))                         # train_generator.py:183
+            s_c, s_g = float(g.uniform(0.1, 1.0)), float(g.uniform(0.1, 1.0))   # :194 (unused when nb == 0), :226
+            nbs.append(nb); sc.append(s_c); sg.append(s_g)
+            netg.eval(); clean.eval(); netc.train(); opt_c.zero_grad()
+            chg = inputs[trg[:nb]]
+            ibd = backdoor(netg, chg, s_c) if nb else chg
+            tot_in = torch.cat([ibd, inputs[trg[nb:]], inputs[ntrg]], 0)
+            tot_t = torch.cat([bd_targets[trg[:nb]], targets[trg[nb:]], targets[ntrg]], 0)
+            ce(netc(tot_in), tot_t).backward()
+            opt_c.step()
+            netc.eval(); netg.train(); opt_g.zero_grad()
+            ibd = backdoor(netg, inputs, s_g)
+            loss = ce(netc(ibd), bd_targets) + 0.02 * F.mse_loss(ibd, inputs) + 0.8 * ce(clean(ibd), targets)
+            loss.backward()
+            opt_g.step()
+        netc.eval(); netg.eval()
+        cnt = dict.fromkeys(keys_b, 0)
+        sig = []
+        with torch.no_grad():
+            for x, t in test_batches:
+                cnt["clean"] += int((netc(x).argmax(1) == t).sum())
+                cnt["cm"] += int((clean(x).argmax(1) == t).sum())
+                nt = (t != 0).nonzero()[:, 0]
+                s_e = float(g.uniform(0.1, 1.0))
+                sig.append(s_e)
+                xb = backdoor(netg, x[nt], s_e)
+                tb = torch.zeros_like(t[nt])
+                cnt["bd_n"] += len(nt)
+                cnt["bd"] += int((netc(xb).argmax(1) == tb).sum())
+                cmb = clean(xb).argmax(1)
+                cnt["cm_ba"] += int((cmb == t[nt]).sum())
+                cnt["cm_asr"] += int((cmb == tb).sum())
+        ev_sig.append(sig)
+        for k in keys_b:
+            ev_b[k].append(cnt[k])
+        acc_clean, acc_bd = cnt["clean"] * 100.0 / cfg["n_test"], cnt["bd"] * 100.0 / cnt["bd_n"]
+        if acc_clean > best_c or (acc_clean == best_c and acc_bd > best_b):    # :433
+            best_c, best_b, best_g = acc_clean, acc_bd, copy.deepcopy(netg.state_dict())
+            out["B/best_epoch"] = np.int64(ep)
+        print("  B epoch %d: %s  (%.0f s)" % (ep, cnt, time.time() - t0), flush=True)
+    out["B/perm"], out["B/num_bd"], out["B/sigma_c"], out["B/sigma_g"] = np.stack(perms_b), np.array(nbs), np.array(sc), np.array(sg)
+    out["B/eval_sigma"] = np.array(ev_sig)
+    for k in keys_b:
+        out["B/eval_" + k] = np.array(ev_b[k])
+    netg.load_state_dict(best_g)
+    netg.eval()
+    for p_ in netg.parameters():
+        p_.requires_grad_(False)
+    summarize(netg.state_dict().items(), out, "B/final_netg")
+
+    # ---- C: victim
+    ids = [i for i, l in enumerate(ytr.tolist()) if l == 0]
+    num = int(0.5 * len(ids))
+    flags = np.zeros(n, np.bool_)
+    flags[g.choice(np.array(ids), size=num, replace=False)] = True       # utils/dataloader_cleanbd.py:142-150
+    out["C/poisoned"] = flags
+    poisoned = torch.from_numpy(flags)
+    torch.manual_seed(cfg["seeds"]["victim"])
+    vic = PreActResNet18()
+    opt_v = sgd(vic)
+    perms_c, sig_c, ev_sig_c, ev_c = [], [], [], {"clean": [], "bd": [], "bd_n": []}
+    best, best_state = -1.0, None
+    for ep in range(cfg["epochs_c"]):
+        perm = g.permutation(n)
+        perms_c.append(perm)
+        vic.train()
+        for i in range(0, n, bs):
+            idx = torch.from_numpy(perm[i:i + bs])
+            inputs, targets, pz = xtr[idx], ytr[idx], poisoned[idx]
+            trg, ntrg = pz.nonzero()[:, 0], (~pz).nonzero()[:, 0]
+            opt_v.zero_grad()
+            if len(trg):
+                s_v = float(g.uniform(0.1, 1.0))
+                sig_c.append(s_v)
+                with torch.no_grad():
+                    ibd = backdoor(netg, inputs[trg], s_v)
+            else:
+                ibd = inputs[trg]
+            tot_in = torch.cat([ibd, inputs[ntrg]], 0)
+            tot_t = torch.cat([torch.zeros_like(targets)[trg], targets[ntrg]], 0)
+            ce(vic(tot_in), tot_t).backward()
+            opt_v.step()
+        vic.eval()
+        cnt, sig = {"clean": 0, "bd": 0, "bd_n": 0}, []
+        with torch.no_grad():
+            for x, t in test_batches:
+                cnt["clean"] += int((vic(x).argmax(1) == t).sum())
+                nt = (t != 0).nonzero()[:, 0]
+                s_e = float(g.uniform(0.1, 1.0))
+                sig.append(s_e)
+                cnt["bd"] += int((vic(backdoor(netg, x[nt], s_e)).argmax(1) == 0).sum())
+                cnt["bd_n"] += len(nt)
+        ev_sig_c.append(sig)
+        for k in cnt:
+            ev_c[k].append(cnt[k])
+        if cnt["clean"] > best:
+            best, best_state = cnt["clean"], copy.deepcopy(vic.state_dict())
+            out["C/best_epoch"] = np.int64(ep)
+        print("  C epoch %d: %s  (%.0f s)" % (ep, cnt, time.time() - t0), flush=True)
+    out["C/perm"], out["C/sigma"], out["C/eval_sigma"] = np.stack(perms_c), np.array(sig_c), np.array(ev_sig_c)
+    for k in ev_c:
+        out["C/eval_" + k] = np.array(ev_c[k])
+    vic.load_state_dict(best_state)
+    vic.eval()
+
+    # ---- D: eval.py:108-152
+    cnt, sig = {"clean": 0, "bd_ba": 0, "bd_asr": 0, "bd_n": 0}, []
+    with torch.no_grad():
+        for x, t in test_batches:
+            cnt["clean"] += int((vic(x).argmax(1) == t).sum())
+            nt = (t != 0).nonzero()[:, 0]
+            s_e = float(g.uniform(0.1, 1.0))
+            sig.append(s_e)
+            pb = vic(backdoor(netg, x[nt], s_e)).argmax(1)
+            cnt["bd_ba"] += int((pb == t[nt]).sum())
+            cnt["bd_asr"] += int((pb == 0).sum())
+            cnt["bd_n"] += len(nt)
+    out["D/eval_sigma"] = np.array(sig)
+    for k, v in cnt.items():
+        out["D/" + k] = np.int64(v)
+    print("  D: %s -> clean acc %.3f  Bd BA %.3f  Bd ASR %.3f  (%.0f s)" % (
+        cnt, cnt["clean"] * 100.0 / cfg["n_test"], cnt["bd_ba"] * 100.0 / cnt["bd_n"], cnt["bd_asr"] * 100.0 / cnt["bd_n"],
+        time.time() - t0), flush=True)
+    save(name, out)
+
+
+def golden_end_metric_perturbed():
+    """The same pipeline with a different reduction order inside the CPU kernels (4 threads instead of 8): how far two
+    fp32 runs of the REFERENCE are apart in the end metrics -- the floor under any tolerance on them."""
+    golden_end_metric("end_metric_perturbed.npz", threads=4)
+
+
+
 def _wanet_warp(x, noise, rescale=0.15):
     """train_generator_wanet.py:152-157 with its own calls (F.upsample == F.interpolate)."""
     h = x.shape[-1]
@@ -744,6 +973,9 @@ if __name__ == "__main__":
     golden_step_b128()
     golden_trajectory()
     golden_trajectory_lr2e3()
+    golden_trajectory_celeba()
     golden_eval_victim()
     golden_wanet()
+    golden_wanet_trajectory()
+    golden_end_metric()
     golden_config()

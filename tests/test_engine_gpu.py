@@ -548,6 +548,51 @@ def test_backward_plans_do_not_share_weight_gradient_scratch(mods):
         engine.Plan.default_aux_queues = 1
 
 
+def test_plan_replay_in_c_equals_python_replay(mods):
+    """combat_plan_run (csrc/plan.cpp: the launch list walked in C, hand-off events reused) against the Python replay
+    of the same plans: five alternated steps from identical states must leave BIT-identical parameters, momentum,
+    running statistics and metric sums, with the auxiliary weight-gradient queue in play and in line (serial)."""
+    engine, step_mod = mods["engine"], mods["step"]
+    opt = Opt()
+
+    def run(compiled, serial):
+        engine.Plan.compiled = compiled
+        engine.Plan.serial = serial
+        try:
+            netc, clean, netg, netf = (m.cuda() for m in _build(mods, (0, 1, 2, 3)))
+            clean.eval()
+            st = step_mod.AlternatedStep(netc, netg, clean, netf, opt)
+            st.serial = serial
+            for i in range(5):
+                x, t = bench_batch(i, 32)
+                st.run(x.cuda(), t, step_mod.StepRandomness(3 if i != 2 else 0, 0.4, 0.7, [None] * 5))
+            torch.cuda.synchronize()
+            state = {k: v.detach().clone() for m in (netc, netg) for k, v in m.state_dict().items()}
+            return state, st.eC.fp.mom.clone(), st.eG.fp.mom.clone(), st.read_metrics()
+        finally:
+            engine.Plan.compiled, engine.Plan.serial = True, False
+
+    for serial in (False, True):
+        ref, got = run(False, serial), run(True, serial)
+        for k in ref[0]:
+            assert torch.equal(ref[0][k], got[0][k]), (serial, k)
+        assert torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2])
+        assert ref[3] == got[3], (ref[3], got[3])
+
+
+def test_plan_replay_reports_the_failing_call(mods):
+    """A recorded call whose arguments the entry point rejects surfaces as CombatHipError naming the call, as in the
+    Python replay."""
+    engine, lib_mod = mods["engine"], __import__("combat_amd._lib", fromlist=["lib"])
+    P = engine.Plan("probe")
+    buf = torch.zeros(64, device="cuda")
+    P.hold(buf)
+    P.add("ok", lib_mod.lib.combat_memset_zero, buf.data_ptr(), 256)
+    P.add("bad", lib_mod.lib.combat_memset_zero, None, -4)
+    with pytest.raises(lib_mod.CombatHipError, match="probe/bad"):
+        P.run()
+
+
 def _ema(v, a=0.1):
     out, m = [], float(v[0])
     for x in v:

@@ -88,7 +88,11 @@ def test_tile_choice_and_stats_layout_are_host_queries(L):
     a.N, a.H, a.W, a.C, a.P, a.Q, a.K = 128, 32, 32, 64, 32, 32, 64
     a.R = a.S = 3
     a.stride, a.pad, a.kpad, a.rows_pad = 1, 1, 576, 128
-    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_D128x64      # no prologue: DMA-staged tile
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_S128x64      # no prologue, C = K = 64, >= 2 tiles per CU:
+    #                                                                             weight-stationary persistent kernel
+    a.N = 48                                                                    # 384 tiles: the ring kernel
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_D128x64
+    a.N = 128
     a.pro_act = 1
     assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_H128x64      # prologue, big layer: halo 128x64
     rows, rpi = ctypes.c_int32(), ctypes.c_int32()

@@ -166,6 +166,7 @@ DMA_CASES = [
     (4, 32, 64, 64, 11), (3, 16, 128, 64, 11), (5, 8, 128, 64, 11), (9, 4, 512, 512, 11), (7, 4, 256, 256, 0),  # 32-channel tiles
     (3, 32, 64, 64, 14), (2, 16, 128, 128, 14), (7, 8, 128, 64, 14), (5, 8, 64, 128, 14),     # 256-pixel tiles, ragged N
     (3, 32, 64, 64, 16), (2, 32, 128, 128, 16), (3, 16, 128, 128, 16), (5, 16, 64, 128, 16), (2, 16, 256, 64, 16),  # 64-pixel wave tiles
+    (3, 32, 64, 64, 17), (5, 16, 64, 64, 17), (40, 32, 64, 64, 17), (81, 32, 64, 64, 17),   # weight-stationary persistent kernel: 1, 1, 2, 3 tiles per workgroup
 ]
 
 
@@ -198,8 +199,62 @@ def test_conv3x3_dma_forward_and_dgrad(ops, n, hw, c, k, tile):
     assert rel_l2(nchw(dx), torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w), rb(dy), padding=1)) < 4e-3
 
 
+@pytest.mark.parametrize("n,hw", [(3, 32), (40, 32), (81, 32), (128, 32), (67, 16), (200, 16)])
+def test_conv3x3_weight_stationary_equals_ring_kernel(ops, n, hw):
+    """COMBAT_TILE_S128x64 (filter bank resident in LDS, persistent workgroups, two wave groups half a tile apart)
+    against COMBAT_TILE_D128x64 on the same arguments: same tiles, same MFMA order, same fused epilogue, so every
+    output -- raw tensor, activated tensor, statistics rows -- must be BIT-identical, for each of the five epilogue
+    flavours the step launches and for 1 ... 7 tiles per workgroup (odd counts leave the second group a tile short)."""
+    from combat_amd._lib import lib
+    import ctypes
+    c = k = 64
+    w, pc = make_conv(ops, k, c, 3, 1, 1, 40)
+    x = nhwc(torch.randn(n, c, hw, hw, generator=g(41)))
+    dy = nhwc(torch.randn(n, k, hw, hw, generator=g(42)))
+    res = nhwc(torch.randn(n, k, hw, hw, generator=g(43)))
+    xpre = nhwc(torch.relu(torch.randn(n, c, hw, hw, generator=g(44))))
+    sc = dev((torch.rand(k, generator=g(45)) + 0.5) * torch.where(torch.rand(k, generator=g(46)) < 0.2, -1.0, 1.0))
+    sh = dev(torch.randn(k, generator=g(47)) * 0.3)
+    mean, rstd = dev(torch.randn(k, generator=g(48)) * 0.1), dev(torch.rand(k, generator=g(49)) + 0.5)
+    aff = ops.Affine(sc, sh, 0, True, 0.0)
+    cases = {
+        "plain+residual": lambda t, o: ops.conv_args(x, o["y"], pc, 0, add_post=res, tile=t),
+        "activated output": lambda t, o: ops.conv_args(x, o["y"], pc, 0, add_post=res, act_dst=o["act"], act=aff, tile=t),
+        "activated output only": lambda t, o: ops.conv_args(x, None, pc, 0, act_dst=o["act"], act=aff, tile=t),
+        "statistics": lambda t, o: ops.conv_args(x, o["y"], pc, 0, add_post=res, stats_kind=1, tile=t),
+        "eval backward": lambda t, o: ops.conv_args(dy, o["y"], pc, 1, add_pre=res, mask_x=xpre, mask=aff, mask_mul_scale=True,
+                                                     mask_activated=True, add_post=res, tile=t),
+        "train backward": lambda t, o: ops.conv_args(dy, o["y"], pc, 1, add_pre=res, mask_x=xpre, mask=aff, stats_kind=2,
+                                                      xh_mean=mean, xh_rstd=rstd, tile=t),
+    }
+    for name, make in cases.items():
+        outs = []
+        for tile in (10, 17):
+            o = dict(y=torch.zeros(n, hw, hw, k, dtype=bf16, device="cuda"), act=torch.zeros(n, hw, hw, k, dtype=bf16, device="cuda"))
+            a = make(tile, o)
+            assert lib.combat_conv_pick_tile(ctypes.byref(a)) == tile, name
+            if a.stats_kind:
+                rows, rpi = ops.conv_stats_layout(a)
+                o["stats"] = torch.zeros(rows, 2, k, device="cuda")
+                a.stats = o["stats"].data_ptr()
+                o["layout"] = (rows, rpi)
+            ops.conv_launch(a)
+            torch.cuda.synchronize()
+            outs.append(o)
+        for key in outs[0]:
+            if key == "layout":
+                assert outs[0][key] == outs[1][key], name
+            else:
+                assert torch.equal(outs[0][key], outs[1][key]), (name, key, n, hw)
+    # and the automatic choice: the persistent kernel from two tiles per CU upwards
+    a = ops.conv_args(x, torch.empty(n, hw, hw, k, dtype=bf16, device="cuda"), pc, 0)
+    tiles = n * (hw // 16) * (hw // 8)
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) == (17 if tiles >= 512 else (11 if tiles <= 256 else 10))
+
+
 @pytest.mark.parametrize("n,hw,c,k,r,stride,tile,keep_raw", [
     (4, 16, 64, 64, 3, 1, 0, True), (4, 16, 64, 128, 3, 1, 0, False),     # DMA-staged kernel
+    (4, 16, 64, 64, 3, 1, 17, True), (41, 32, 64, 64, 3, 1, 17, False),   # ... weight-stationary persistent form
     (4, 16, 64, 64, 3, 1, 16, True), (3, 32, 64, 128, 3, 1, 16, False),   # ... with 64-pixel wave tiles
     (4, 16, 64, 64, 3, 1, 8, False), (3, 8, 128, 128, 3, 1, 9, True),     # halo kernels
     (4, 16, 64, 128, 3, 2, 0, False), (4, 16, 8, 64, 3, 1, 0, True), (4, 16, 64, 128, 1, 2, 0, True)])  # gather kernel

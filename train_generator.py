@@ -20,7 +20,7 @@ import torch
 import config
 from combat_amd import api, dist as cdist
 from combat_amd.data import get_dataloader
-from combat_amd.log import SummaryWriter, progress_bar
+from combat_amd.log import SummaryWriter, image_grid, progress_bar
 from combat_amd.nets import FrequencyModel, UnetGenerator, configure_dataset, default_classifier
 from combat_amd.step import AlternatedStep, WanetStep, create_targets_bd  # noqa: F401  (re-exported like the reference)
 
@@ -88,6 +88,8 @@ def train(netC, optimizerC, schedulerC, netG, optimizerG, schedulerG, netF, clea
             "CleanModel Bd ASR": m["clean_model_bd_asr"] * 100.0 / ts,
             "L2 Loss": m["loss_l2_sum"] / ts, "Grad L2 Loss": m["loss_grad_l2_sum"] / ts,
             "CleanModel Loss": m["clean_model_loss_sum"] / ts}, epoch)
+    if not epoch % 20 and not isinstance(tf_writer, cdist.NullWriter):    # :310-315: the last batch and its backdoored copy (Phase G's inputs_bd) as an image grid
+        tf_writer.add_image("Images", image_grid(st.inputs, st.bd, opt), global_step=epoch)
     schedulerC.step()
     schedulerG.step()
 

@@ -8,7 +8,7 @@ import torch
 import config
 from combat_amd import api, dist as cdist
 from combat_amd.data import get_dataloader
-from combat_amd.log import SummaryWriter, progress_bar
+from combat_amd.log import SummaryWriter, image_grid, progress_bar
 from combat_amd.nets import UnetGenerator, configure_dataset, default_classifier
 from combat_amd.step import ClassifierStep, create_targets_bd
 
@@ -31,9 +31,12 @@ def train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt):
     if step.N:
         step.read_metrics(reset=True)
     total = 0
+    pair = None
     for batch_idx, (inputs, targets, poisoned) in enumerate(train_dl):
         step.run(inputs.to(opt.device, non_blocking=True), targets, poisoned, lr=optimizerC.param_groups[0]["lr"])
         total += inputs.shape[0]
+        if step.wanet and not batch_idx % 5:       # train_victim_wanet.py:127-133 (every fifth batch with a poisoned image)
+            pair = step.poisoned_pair() or pair
         last = batch_idx == len(train_dl) - 1 or (opt.max_steps and batch_idx + 1 >= opt.max_steps)
         if batch_idx % max(1, opt.log_interval) == 0 or last:
             m = step.read_metrics()
@@ -42,6 +45,8 @@ def train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt):
         if last:
             break
     tf_writer.add_scalars("Clean Accuracy", {"Clean": m["correct"] * 100.0 / total}, epoch)
+    if step.wanet and pair is not None and not isinstance(tf_writer, cdist.NullWriter):   # train_victim_wanet.py:136
+        tf_writer.add_image("Images", image_grid(pair[0], pair[1], opt), global_step=epoch)
     schedulerC.step()
 
 
@@ -72,13 +77,31 @@ def eval(netC, optimizerC, schedulerC, netG, test_dl, best_clean_acc, best_bd_ac
         best_clean_acc, best_bd_acc = acc_clean, acc_bd
         if int(os.environ.get("RANK", 0)) == 0:
             api.sync_momentum_to_optimizer(optimizerC, netC)
-            torch.save({"netC": netC.state_dict(), "schedulerC": schedulerC.state_dict(), "optimizerC": optimizerC.state_dict(),
-                        "netG": netG.state_dict(), "best_clean_acc": acc_clean, "best_bd_acc": acc_bd,
-                        "epoch_current": epoch}, opt.ckpt_path)
+            state = {"netC": netC.state_dict(), "schedulerC": schedulerC.state_dict(), "optimizerC": optimizerC.state_dict(),
+                     "netG": netG.state_dict(), "best_clean_acc": acc_clean, "best_bd_acc": acc_bd, "epoch_current": epoch}
+            if getattr(netG, "arch", "") == "gridgen":          # train_victim_wanet.py:199
+                state["grid_rescale"] = opt.grid_rescale
+            torch.save(state, opt.ckpt_path)
     return best_clean_acc, best_bd_acc
 
 
-def main():
+def load_generator(netG, load_path, opt):
+    """The frozen generator of the attack (:262-280).  A checkpoint of the other trigger family is refused by name
+    instead of by a state-dict key mismatch deep inside torch."""
+    sd = torch.load(load_path, map_location=opt.device, weights_only=True)["netG"]
+    is_grid = any(k.startswith("fc1.") for k in sd)
+    want_grid = getattr(netG, "arch", "") == "gridgen"
+    if is_grid != want_grid:
+        raise SystemExit("Error: {} holds a {} generator; use {}".format(
+            load_path, "GridGenerator (WaNet)" if is_grid else "UnetGenerator",
+            "train_victim_wanet.py" if is_grid else "train_victim.py"))
+    netG.load_state_dict(sd)
+    netG.eval()
+    netG.requires_grad_(False)      # :279-280
+
+
+def main(get_model=None, wanet=False):
+    get_model = get_model or globals()["get_model"]
     opt = config.get_arguments().parse_args()
     configure_dataset(opt)
     rank, local_rank, world = cdist.init()
@@ -93,7 +116,8 @@ def main():
     train_dl = get_dataloader(opt, True, poisoned=True, rank=rank, world=world)
     test_dl = get_dataloader(opt, False, shuffle=False, poisoned=True, rank=rank, world=world)
     netC, optimizerC, schedulerC, netG = get_model(opt)
-    mode = opt.saving_prefix
+    # train_victim.py:255-257 saves under <prefix>/, train_victim_wanet.py:241-243 under <prefix>_clean/
+    mode = "{}_clean".format(opt.saving_prefix) if wanet else opt.saving_prefix
     opt.ckpt_folder = os.path.join(opt.checkpoints, mode, opt.dataset)
     opt.ckpt_path = os.path.join(opt.ckpt_folder, "{}_{}.pth.tar".format(opt.dataset, mode))
     opt.log_dir = os.path.join(opt.ckpt_folder, "log_dir")
@@ -102,9 +126,7 @@ def main():
     if not os.path.exists(load_path):
         print("Error: {} not found".format(load_path))
         exit()
-    netG.load_state_dict(torch.load(load_path, map_location=opt.device, weights_only=True)["netG"])
-    netG.eval()
-    netG.requires_grad_(False)      # :279-280
+    load_generator(netG, load_path, opt)
     best_clean_acc = best_bd_acc = 0.0
     epoch_current = 0
     if opt.continue_training and os.path.exists(opt.ckpt_path):
