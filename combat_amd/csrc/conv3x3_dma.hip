@@ -533,14 +533,31 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
         hdec[j] = (row < G::HROWS && hx < TW + 2) ? (hx | (hy << 8)) : -1;
         hrel[j] = (((hy - 1) * W + hx - 1) * C + chunk * 8) * 2;
     }
-    int t_img = 0, t_oy = 0, t_ox = 0;
-    auto tile_coords = [&](int k) __attribute__((always_inline)) {   // tile k of this group
-        const int tm = first + grp + 2 * k;
-        const int tx_ = tm % p.tiles_x, r = tm / p.tiles_x;
-        t_ox = tx_ * TW;
-        t_oy = (r % p.tiles_y) * G::TH;
+    // tile coordinates of this group's current tile (tile index, column / row of tiles, image): divided out once,
+    // then stepped by two tiles with carries (the divisions were ~300 cycles of every half-period)
+    int tm_cur = first + grp, c_tx = 0, c_ty = 0, t_img = 0, t_oy = 0, t_ox = 0;
+    {
+        const int r = tm_cur / p.tiles_x;
+        c_tx = tm_cur - r * p.tiles_x;
         t_img = r / p.tiles_y;
-        return tm;
+        c_ty = r - t_img * p.tiles_y;
+        t_ox = c_tx * TW;
+        t_oy = c_ty * G::TH;
+    }
+    auto next_tile = [&]() __attribute__((always_inline)) {
+        tm_cur += 2;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (++c_tx == p.tiles_x) {
+                c_tx = 0;
+                if (++c_ty == p.tiles_y) {
+                    c_ty = 0;
+                    ++t_img;
+                }
+            }
+        }
+        t_ox = c_tx * TW;
+        t_oy = c_ty * G::TH;
     };
     // The DMA is issued from inline asm because the compiler guards the first LDS read behind an LDS-DMA it knows of
     // with s_waitcnt vmcnt(0) -- here that would park the epilogue (whose transposition image is LDS) until the next
@@ -583,13 +600,63 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
     }
 
     const unsigned dst_bytes = (unsigned)(a.N * p.PQ) * (unsigned)a.K * 2u;
-    auto tile_row_off = [&](int row) -> long {
-        const int tx = row & (TW - 1), ty = (row >> 4) & (G::TH - 1);
-        return (long)((t_img * H + t_oy + ty) * W + t_ox + tx) * a.K;
+    // byte offset of this lane's epilogue items relative to the tile's first pixel (every tile lies inside the tensor)
+    unsigned erel[EC::EQ];
+#pragma unroll
+    for (int q = 0; q < EC::EQ; ++q) {
+        const int row = gw * 32 + (q * 64 + lane) / EC::NC;
+        erel[q] = (unsigned)((((row >> 4) * W + (row & (TW - 1))) * a.K + (lane % EC::NC) * 8) * 2);
+    }
+    constexpr bool kUsesMask = FL < 0 || (FL & EF_MASK), kUsesTabs = FL < 0 || (FL & (EF_MASK | EF_ACT));
+    // operand fetches of the current tile: only what this flavour can read, and only the tensors that exist
+    auto ws_fetch = [&](EpiRegs<T> &r) __attribute__((always_inline)) {
+        const unsigned org = (unsigned)(((t_img * H + t_oy) * W + t_ox) * a.K * 2);
+#pragma unroll
+        for (int q = 0; q < EC::EQ; ++q) r.evoff[q] = org + erel[q];
+        if (a.add_pre) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_pre), 0, dst_bytes, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < EC::EQ; ++q) r.e_pre[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, r.evoff[q], 0, 0);
+        }
+        if constexpr (kUsesMask) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.mask_x), 0, a.mask_x ? dst_bytes : 0u, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < EC::EQ; ++q) r.e_x[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, r.evoff[q], 0, 0);
+        }
+        if (a.add_post) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.add_post), 0, dst_bytes, 0x00020000);
+#pragma unroll
+            for (int q = 0; q < EC::EQ; ++q) r.e_post[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, r.evoff[q], 0, 0);
+        }
+    };
+    auto ws_touch = [&](EpiRegs<T> &r) __attribute__((always_inline)) {   // (see epi_touch)
+#pragma unroll
+        for (int q = 0; q < EC::EQ; ++q) {
+            asm volatile("" : "+v"(r.e_pre[q]), "+v"(r.e_post[q]));
+            if constexpr (kUsesMask) asm volatile("" : "+v"(r.e_x[q]));
+        }
     };
     EpiRegs<T> epi;
+    if constexpr (kUsesTabs) {   // the (scale, shift) table pair of this flavour: per channel, the same for every tile
+        // (buffer loads: an absent table is an empty resource and reads zeros -- no select on the loaded value, which
+        // would make the compiler wait for the load, and with it for the weight DMA in front of it, right here)
+        const float *tab_sc = a.mask_x ? a.mask_scale : a.act_scale, *tab_sh = a.mask_x ? a.mask_shift : a.act_shift;
+        const __amdgpu_buffer_rsrc_t r_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab_sc), 0, tab_sc ? BN * 4u : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_sh = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tab_sh), 0, tab_sh ? BN * 4u : 0u, 0x00020000);
+        const int tb = (lane % EC::NC) * 32;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            epi.t_sc[h2] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_sc, tb + 16 * h2, 0, 0));
+            epi.t_sh[h2] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r_sh, tb + 16 * h2, 0, 0));
+        }
+    } else {
+        epi.t_sc[0] = epi.t_sc[1] = epi.t_sh[0] = epi.t_sh[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     f32x4_t acc[T::FN][T::FM];
 
+    // One k-step = FM + FN fragment reads for the NEXT k-step and FM * FN MFMAs of the current one, interleaved one
+    // read per MFMA gap: an MFMA holds the SIMD's vector issue for 8 of its 16 cycles, so a ds_read_b128 issued inside
+    // the gap is (nearly) free, while a block of six reads in front of the MFMA block costs its full issue time.
     auto read_frags = [&](bf16x8_t (&fp)[T::FM], bf16x8_t (&fw)[T::FN], auto t_tag, auto ks_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value, ks = decltype(ks_tag)::value;
         constexpr int dy = t / 3, dx = t % 3;
@@ -599,14 +666,21 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
         for (int j = 0; j < T::FM; ++j) fp[j] = *reinterpret_cast<const bf16x8_t *>(hb + pa[ks][j][dx]);
 #pragma unroll
         for (int i = 0; i < T::FN; ++i) fw[i] = *reinterpret_cast<const bf16x8_t *>(wb + wa[ks] + i * 2048);
-        __builtin_amdgcn_sched_barrier(0);
     };
-    auto mfma_frags = [&](const bf16x8_t (&fp)[T::FM], const bf16x8_t (&fw)[T::FN]) __attribute__((always_inline)) {
+    auto mfma_frags = [&](const bf16x8_t (&fp)[T::FM], const bf16x8_t (&fw)[T::FN], bool with_reads) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < T::FN; ++i)
 #pragma unroll
             for (int j = 0; j < T::FM; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fp[j], acc[i][j], 0, 0, 0);
+        if (with_reads) {
+#pragma unroll
+            for (int r = 0; r < T::FM + T::FN; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, T::FM * T::FN - (T::FM + T::FN), 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     using I0 = std::integral_constant<int, 0>;
@@ -614,18 +688,9 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
 
     // ---- prologue: the filter bank and this group's first halo patch must have landed before anyone reads LDS; the
     // first tile's epilogue operands are fetched behind that wait and land under its MFMAs
-    int tm_cur = 0;
-    if (ng > 0) {
-        tm_cur = tile_coords(0);
-        issue_halo();
-    }
+    if (ng > 0) issue_halo();
     WS_STAMP(1);
     wait_vm_lgkm0<0>();
-    __builtin_amdgcn_sched_barrier(0);
-    if (ng > 0) {
-        epi_init<T>(epi, lane, gw, 0, tile_row_off);
-        epi_fetch<T>(epi, a, dst_bytes, lane, 0);
-    }
     block_barrier();
     // ---- group B runs half a period behind group A: one barrier interval = one half-period, in which one group
     // computes a tile and the other finishes its previous one.  Both groups run the SAME straight-line loop body
@@ -634,23 +699,30 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
     if (grp == 1) block_barrier();
     WS_STAMP(3);
     for (int k = 0; k < ng; ++k) {
+        // this tile's epilogue operands: fetched now, landing under its MFMAs, consumed in the same iteration (not
+        // carried around the loop: the compiler copied loop-carried load results at the latch, behind a full wait)
+        ws_fetch(epi);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < T::FN; ++i)
 #pragma unroll
             for (int j = 0; j < T::FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         {
             bf16x8_t fpA[T::FM], fwA[T::FN], fpB[T::FM], fwB[T::FN];
+            __builtin_amdgcn_s_setprio(1);      // the matrix pipe's wave goes first; its SIMD partner is in an epilogue
             read_frags(fpA, fwA, I0{}, I0{});
+            __builtin_amdgcn_sched_barrier(0);
 #define COMBAT_WS_POS(t)                                                                       \
     {                                                                                          \
         read_frags(fpB, fwB, std::integral_constant<int, t>{}, I1{});                          \
-        mfma_frags(fpA, fwA);                                                                  \
+        mfma_frags(fpA, fwA, true);                                                            \
         if (t < 8) read_frags(fpA, fwA, std::integral_constant<int, (t + 1) % 9>{}, I0{});     \
-        mfma_frags(fpB, fwB);                                                                  \
+        mfma_frags(fpB, fwB, t < 8);                                                           \
     }
             COMBAT_WS_POS(0) COMBAT_WS_POS(1) COMBAT_WS_POS(2) COMBAT_WS_POS(3) COMBAT_WS_POS(4)
             COMBAT_WS_POS(5) COMBAT_WS_POS(6) COMBAT_WS_POS(7) COMBAT_WS_POS(8)
 #undef COMBAT_WS_POS
+            __builtin_amdgcn_s_setprio(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's fragment reads are back: its patch may be overwritten
         WS_STAMP(4 + 6 * k);
@@ -658,9 +730,9 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
         WS_STAMP(5 + 6 * k);
         const int tm_done = tm_cur;
         const bool more = k + 1 < ng;
-        epi_touch<T>(epi);   // (the operand fetches have landed: say so before the DMA below enters the wait counts)
+        ws_touch(epi);       // (the operand fetches have landed: say so before the DMA below enters the wait counts)
         if (more) {          // the patch of this group's next tile lands while the other group computes
-            tm_cur = tile_coords(k + 1);
+            next_tile();
             issue_halo();
         }
         WS_STAMP(6 + 6 * k);
@@ -673,11 +745,6 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
                                  WS_STAMP(8 + 6 * k);
                                  __builtin_amdgcn_sched_barrier(0);
                              });
-        if (more) {
-            __builtin_amdgcn_sched_barrier(0);
-            epi_init<T>(epi, lane, gw, 0, tile_row_off);
-            epi_fetch<T>(epi, a, dst_bytes, lane, 0);
-        }
         WS_STAMP(9 + 6 * k);
         block_barrier();
     }

@@ -477,6 +477,9 @@ struct GatherPair {
 // leaves idle instead of paying a dependent 12-17 us launch of their own.
 template <int BN, int NS>
 __global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_kernel(const GatherPair pp) {
+    // (the second problem starts at a multiple of eight, so that its `index & 7` is again the blocks' XCD group: the
+    // up-to-seven workgroups in between have nothing to do)
+    if (blockIdx.x >= (unsigned)pp.n0 && blockIdx.x < (unsigned)pp.p[1].block_base) return;
     conv_gather_dma_body<BN, false, NS>(pick(pp.p[0], pp.p[1], pp.n0));
 }
 template <int BN>
@@ -626,9 +629,10 @@ void fill(const combat_conv_args *a, GatherParams &p) {
 
 template <int BN>
 int launch(const combat_conv_args *a, hipStream_t st) {
-    static GatherPair pp;    // (filled per call, passed by value)
+    GatherPair pp;           // (filled per call, passed by value: no host state shared between callers)
     GatherParams &p = pp.p[0];
     fill<BN>(a, p);
+    pp.p[1].block_base = 0;
     constexpr int stage = 128 * 128 + BN * 128;
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
     constexpr int smem = (3 * stage > ep ? 3 * stage : ep) + 1024;   // (+ the weight prefetch's scratch KB)
@@ -739,7 +743,7 @@ bool conv_gather_dma_parity_split(const combat_conv_args *a) {
 namespace {
 template <int BN>
 int launch_pair(const combat_conv_args *a, const combat_conv_args *b, hipStream_t st) {
-    static GatherPair pp;      // (2 x ~400 B of kernel arguments; filled per call, passed by value)
+    GatherPair pp;             // (2 x ~400 B of kernel arguments; filled per call, passed by value)
     fill<BN>(a, pp.p[0]);
     fill<BN>(b, pp.p[1]);
     if (pp.p[0].splits > 1 || pp.p[1].splits > 1) return 1;   // split reductions have a finish launch each: not grouped
@@ -756,9 +760,10 @@ int launch_pair(const combat_conv_args *a, const combat_conv_args *b, hipStream_
     // (tried: the two problems' workgroups alternating in groups of eight, so that the short one runs beside the long
     // one from the start instead of as a tail -- same launch time, same step)
     const int n0 = pp.p[0].tiles_m * pp.p[0].tiles_n, n1 = pp.p[1].tiles_m * pp.p[1].tiles_n;
+    const int base1 = (n0 + 7) & ~7;
     pp.n0 = n0;
-    pp.p[1].block_base = n0;
-    hipLaunchKernelGGL(kern, dim3(n0 + n1), dim3(256), smem, st, pp);
+    pp.p[1].block_base = base1;
+    hipLaunchKernelGGL(kern, dim3(base1 + n1), dim3(256), smem, st, pp);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

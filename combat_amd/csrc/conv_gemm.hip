@@ -386,27 +386,9 @@ extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows
     return COMBAT_OK;
 }
 
-extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream);
-
-// Two convolutions with no data dependence between them (neither reads what the other writes): one launch when both take
-// the gather kernel with the same channel tile and unsplit reductions, otherwise a, then b.
-extern "C" int combat_conv_gemm_pair(const combat_conv_args *a, const combat_conv_args *b, void *stream) {
-    COMBAT_PLAN_HOOK(combat_conv_gemm_pair, a, b);
-    if (!a || !b) return COMBAT_EINVAL;
-    const int ta = pick_tile(a), tb = pick_tile(b);
-    const bool gather = (ta == COMBAT_TILE_G128x64 || ta == COMBAT_TILE_G128x32) && ta == tb;
-    if (gather && a->src && b->src && a->wpack && b->wpack && (a->dst || a->act_dst) && (b->dst || b->act_dst) &&
-        a->stats_kind >= 0 && a->stats_kind <= 2 && b->stats_kind >= 0 && b->stats_kind <= 2 && (!a->stats_kind || a->stats) &&
-        (!b->stats_kind || b->stats)) {
-        const int rc = conv_gather_dma_pair_launch(a, b, as_stream(stream));
-        if (rc != 1) return rc;
-    }
-    const int rc = combat_conv_gemm(a, stream);
-    return rc ? rc : combat_conv_gemm(b, stream);
-}
-
-extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
-    COMBAT_PLAN_HOOK(combat_conv_gemm, a);
+// argument checks shared by combat_conv_gemm and combat_conv_gemm_pair (the pair promises results equal to two single
+// calls: it must also reject what they reject, before any kernel dereferences a shape)
+static int validate_conv_args(const combat_conv_args *a) {
     if (!a || !a->src || !a->wpack || (!a->dst && !a->act_dst)) return COMBAT_EINVAL;
     if (a->act_dst && (!a->act_scale || !a->act_shift)) return COMBAT_EINVAL;
     if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->P <= 0 || a->Q <= 0) return COMBAT_EINVAL;
@@ -420,15 +402,37 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     if (a->mask_mul_scale && !a->mask_scale) return COMBAT_EINVAL;
     if (a->stats_kind < 0 || a->stats_kind > 2 || (a->stats_kind && !a->stats)) return COMBAT_EINVAL;
     if (a->stats_kind == 2 && (!a->mask_x || !a->xh_mean || !a->xh_rstd)) return COMBAT_EINVAL;
+    if (ilog2_exact(a->C) < 0) return COMBAT_EINVAL;   // channel counts on this path are powers of two
+    if ((long)a->N * a->P * a->Q > 0x7fffffffL / 8) return COMBAT_EINVAL;
+    return COMBAT_OK;
+}
+
+extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream);
+
+// Two convolutions with no data dependence between them (neither reads what the other writes): one launch when both take
+// the gather kernel with the same channel tile and unsplit reductions, otherwise a, then b.
+extern "C" int combat_conv_gemm_pair(const combat_conv_args *a, const combat_conv_args *b, void *stream) {
+    COMBAT_PLAN_HOOK(combat_conv_gemm_pair, a, b);
+    if (validate_conv_args(a) != COMBAT_OK || validate_conv_args(b) != COMBAT_OK) return COMBAT_EINVAL;
+    const int ta = pick_tile(a), tb = pick_tile(b);
+    const bool gather = (ta == COMBAT_TILE_G128x64 || ta == COMBAT_TILE_G128x32) && ta == tb;
+    if (gather) {
+        const int rc = conv_gather_dma_pair_launch(a, b, as_stream(stream));
+        if (rc != 1) return rc;
+    }
+    const int rc = combat_conv_gemm(a, stream);
+    return rc ? rc : combat_conv_gemm(b, stream);
+}
+
+extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
+    COMBAT_PLAN_HOOK(combat_conv_gemm, a);
+    if (validate_conv_args(a) != COMBAT_OK) return COMBAT_EINVAL;
     ConvParams p;
     p.a = *a;
     p.c_shift = ilog2_exact(a->C);
     p.s_shift = ilog2_exact(a->stride);
-    if (p.c_shift < 0) return COMBAT_EINVAL;  // channel counts on this path are powers of two
     p.PQ = a->P * a->Q;
-    const long M = (long)a->N * p.PQ;
-    if (M > 0x7fffffffL / 8) return COMBAT_EINVAL;
-    p.M = (int)M;
+    p.M = (int)((long)a->N * p.PQ);
     p.ntaps = a->R * a->S;
     p.nkt = a->kpad / 64;
     // only the steps that contain real taps are walked

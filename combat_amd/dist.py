@@ -69,11 +69,12 @@ class GradReducer:
     def __init__(self, flat_grad: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None):
         self.flat, self.ranges, self.group = flat_grad, list(ranges), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.force = os.environ.get("COMBAT_FORCE_ALLREDUCE", "0") == "1"   # (see step.FORCE_ALLREDUCE)
         self._pending = []
 
     def launch(self, i: int) -> None:
         """Start bucket i (call as soon as the backward has produced it)."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         lo, hi = self.ranges[i]
         self._pending.append(dist.all_reduce(self.flat[lo:hi], group=self.group, async_op=True))

@@ -1571,6 +1571,26 @@ class _GeneratorFn(torch.autograd.Function):
             "differentiate through combat_amd.step.AlternatedStep; module(x) is inference-only")
 
 
+class _GridFn(torch.autograd.Function):
+    """[B, 2, S, S] field of a GridGenerator: the same for every sample (see GridEngine).  Like the other modules'
+    `module(x)` it is inference-only: a backward through it raises instead of handing the caller's own training
+    loop a silent zero gradient (the differentiated path is combat_amd.step.WanetStep)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        eng = module._net_engine()
+        st = torch.cuda.current_stream().cuda_stream
+        b1, w2, b2 = eng._head()
+        ops.check(lib.combat_grid_head_fwd(b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), eng.nf, eng.nout,
+                                           eng.field.data_ptr(), st), "combat_grid_head_fwd")
+        return eng.field.view(1, 2, eng.S, eng.S).expand(x.shape[0], -1, -1, -1).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError(
+            "differentiate through combat_amd.step.WanetStep; module(x) is inference-only")
+
+
 def module_forward(module, x: torch.Tensor) -> torch.Tensor:
     """The reference's `module(x)` call signature (float32 NCHW in, float32 out) on the HIP path."""
     if x.device.type != "cuda":
@@ -1580,13 +1600,8 @@ def module_forward(module, x: torch.Tensor) -> torch.Tensor:
         return _GeneratorFn.apply(module, x, *params)
     if module.arch in ("preact_resnet18", "resnet18"):
         return _ClassifierFn.apply(module, x, *params)
-    if module.arch == "gridgen":     # [B, 2, S, S]: the same field for every sample (see GridEngine)
-        eng = module._net_engine()
-        st = torch.cuda.current_stream().cuda_stream
-        b1, w2, b2 = eng._head()
-        ops.check(lib.combat_grid_head_fwd(b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), eng.nf, eng.nout,
-                                           eng.field.data_ptr(), st), "combat_grid_head_fwd")
-        return eng.field.view(1, 2, eng.S, eng.S).expand(x.shape[0], -1, -1, -1).clone()
+    if module.arch == "gridgen":
+        return _GridFn.apply(module, x, *params)
     if module.arch == "freq":
         eng = module._net_engine()
         eng.refresh()

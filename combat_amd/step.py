@@ -115,11 +115,15 @@ def shared_stream(device, kind: str, priority: int = 0) -> torch.cuda.Stream:
     return s
 
 
+FORCE_ALLREDUCE = os.environ.get("COMBAT_FORCE_ALLREDUCE", "0") == "1"   # issue the bucketed all-reduces even at world size 1
+#                                                                          (tests: RCCL's streams beside the step's on ONE GPU)
+
+
 def backward_allreduce(plan, eng, pg, world: int, reducers: dict, prof=None) -> None:
     """Run a backward plan; with several ranks, all-reduce the flat gradient buffer in buckets, each launched as
     soon as the plan has enqueued the kernels that complete it (`Plan.mark`), so that the first buckets travel
     while the rest of the backward still runs.  `reducers` caches the GradReducer per plan."""
-    if world == 1:
+    if world == 1 and not (FORCE_ALLREDUCE and pg is not None):
         plan.run(prof)
         return
     red = reducers.get(id(plan))

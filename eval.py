@@ -11,7 +11,7 @@ from combat_amd import api
 from combat_amd import dist as cdist
 from combat_amd.data import get_dataloader
 from combat_amd.log import SummaryWriter, progress_bar
-from combat_amd.nets import UnetGenerator, configure_dataset, default_classifier
+from combat_amd.nets import GridGenerator, UnetGenerator, configure_dataset, default_classifier
 from combat_amd.step import create_targets_bd
 
 
@@ -52,12 +52,18 @@ def main():
     opt.ckpt_folder = os.path.join(opt.checkpoints, "{}_clean".format(mode), opt.dataset)
     opt.log_dir = os.path.join(opt.ckpt_folder, "log_dir")
     os.makedirs(opt.log_dir, exist_ok=True)
-    for net, key, ck in ((netC, "netC", opt.load_checkpoint_clean), (netG, "netG", opt.load_checkpoint)):
+    for key, ck in (("netC", opt.load_checkpoint_clean), ("netG", opt.load_checkpoint)):
         path = os.path.join(opt.checkpoints, ck or "", opt.dataset, "{}_{}.pth.tar".format(opt.dataset, ck))
         if not os.path.exists(path):
             print("Error: {} not found".format(path))
             exit()
-        net.load_state_dict(torch.load(path, map_location=opt.device, weights_only=True)[key])
+        sd = torch.load(path, map_location=opt.device, weights_only=True)[key]
+        if key == "netG" and any(k.startswith("fc1.") for k in sd):
+            # a WaNet generator (train_generator_wanet.py / train_victim_wanet.py checkpoints; the reference has no
+            # stand-alone evaluation script for them: its eval.py builds a UnetGenerator and fails on the keys)
+            netG = GridGenerator(opt).to(opt.device)
+        net = netC if key == "netC" else netG
+        net.load_state_dict(sd)
         net.eval()
     eval(netC, netG, test_dl, SummaryWriter(log_dir=opt.log_dir), opt)
 

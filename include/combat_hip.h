@@ -20,7 +20,11 @@
  *   - packed weights: bf16 [rows_pad][kpad], k = tap * C + c, zero padded
  *     (rows_pad % 128 == 0 or == 16, kpad % 64 == 0);
  *   - fp32 master weights / gradients: [Cout][R][S][Cin] physical order, i.e. a torch OIHW
- *     tensor in channels_last memory format (values and state_dict layout unchanged).
+ *     tensor in channels_last memory format (values and state_dict layout unchanged);
+ *   - threading: ONE launching thread and ONE device per process (the one-rank-per-GPU model of
+ *     INTEGRATION.md).  Entry points keep no kernel-argument state between calls, but the
+ *     "dynamic LDS size set" flags of the kernels are per process (not per device), and plan
+ *     recording (combat_plan_record) arms the calling thread only.
  */
 #ifndef COMBAT_HIP_H
 #define COMBAT_HIP_H

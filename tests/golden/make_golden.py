@@ -586,7 +586,7 @@ def _to_float(u8):
     return (torch.from_numpy(u8).float() / 255 - 0.5) / 0.5        # ToTensor + Normalize(0.5, 0.5) (utils/dataloader.py:35-39)
 
 
-END_CFG = dict(n_train=2048, n_test=1024, bs=128, epochs_a=4, epochs_b=6, epochs_c=6, lr=1e-2, noise_rate=0.08, signal=0.07,
+END_CFG = dict(n_train=2048, n_test=1024, bs=128, epochs_a=6, epochs_b=6, epochs_c=8, lr=1e-2, noise_rate=0.08, signal=0.15,
                seed_train=1234, seed_test=4321, seeds=dict(clean=11, netc=12, netg=13, victim=14), draw_seed=777)
 
 
@@ -816,6 +816,73 @@ def _wanet_warp(x, noise, rescale=0.15):
     return F.grid_sample(x, grid, align_corners=True), noise_grid
 
 
+def golden_victim_wanet():
+    """One batch of train_victim_wanet.py:72-112 (D3 intent: ntrg = ~poisoned, :86 as shipped is the same
+    ``(poisoned is False).nonzero()`` defect) and two evaluation batches of :150-181, through the reference's
+    PreActResNet18 and GridGenerator with its own F.upsample / F.grid_sample calls.  The generator head is given
+    non-trivial values first (a freshly initialised one warps by < 1e-2 of a pixel)."""
+    out = {}
+
+    class WOpt:
+        s = 2
+
+    torch.manual_seed(0)
+    netc = randomize_bn_buffers(PreActResNet18(), 500)
+    torch.manual_seed(2)
+    netg = GridGenerator(WOpt()).eval()
+    with torch.no_grad():
+        netg.fc1.bias.normal_(0, 1.0, generator=rng(31))
+        netg.fc2.weight.normal_(0, 0.5, generator=rng(32))
+        netg.fc2.bias.normal_(0, 0.5, generator=rng(33))
+    for p_ in netg.parameters():
+        p_.requires_grad_(False)
+    out["seeds"], out["bn_seed"], out["head_seeds"] = np.array([0, 2]), np.int64(500), np.array([31, 32, 33])
+    summarize([(k, v) for k, v in netg.state_dict().items() if k.startswith("fc")], out, "netg")
+    # ---- evaluation batches (:150-181): clean accuracy, warped non-target images counted against the target
+    netc.eval()
+    keys = ("clean_n", "clean_correct", "bd_n", "bd_correct", "bd_ba")
+    tr = {k: [] for k in keys}
+    for s_, b in enumerate((64, 37)):
+        x = synth_images(b, 32, 8500 + s_)
+        t = torch.randint(0, 10, (b,), generator=rng(8600 + s_))
+        with torch.no_grad():
+            pc = netc(x)
+            nt = (t != 0).nonzero()[:, 0]
+            ibd, _ = _wanet_warp(x[nt], netg(x[nt]))
+            pb = netc(ibd)
+        for k, v in zip(keys, (b, int((pc.argmax(1) == t).sum()), len(nt), int((pb.argmax(1) == 0).sum()), int((pb.argmax(1) == t[nt]).sum()))):
+            tr[k].append(v)
+        out["eval%d/inputs_bd_sum" % s_] = np.float64(ibd.double().sum())
+    for k in keys:
+        out["eval/" + k] = np.array(tr[k])
+    out["eval/batch"], out["eval/seeds"] = np.array([64, 37]), np.array([8500, 8600])
+    # ---- one training batch
+    b = 48
+    x = synth_images(b, 32, 8700)
+    t = torch.randint(0, 10, (b,), generator=rng(8701))
+    t[:6] = 0
+    poisoned = torch.zeros(b, dtype=torch.bool)
+    poisoned[[0, 2, 5]] = True
+    out["victim/poisoned"], out["victim/seeds"] = poisoned.numpy(), np.array([8700, 8701])
+    opt_c = torch.optim.SGD(netc.parameters(), 1e-2, momentum=0.9, weight_decay=5e-4, nesterov=True)
+    netc.train()
+    opt_c.zero_grad()
+    trg, ntrg = poisoned.nonzero()[:, 0], (~poisoned).nonzero()[:, 0]
+    ibd, _ = _wanet_warp(x[trg], netg(x[trg]))
+    out["victim/inputs_bd"] = ibd.numpy()
+    tot_in = torch.cat([ibd, x[ntrg]], 0)
+    tot_t = torch.cat([torch.zeros_like(t)[trg], t[ntrg]], 0)
+    preds = netc(tot_in)
+    loss = torch.nn.CrossEntropyLoss()(preds, tot_t)
+    loss.backward()
+    out["victim/loss"], out["victim/correct"] = np.float64(loss), np.int64((preds.argmax(1) == tot_t).sum())
+    out["victim/gnorm"] = np.float64(torch.sqrt(sum((p_.grad.double() ** 2).sum() for p_ in netc.parameters())))
+    summarize([(k, p_.grad) for k, p_ in netc.named_parameters()], out, "victim/gp")
+    opt_c.step()
+    summarize(netc.state_dict().items(), out, "victim/after")
+    save("victim_wanet.npz", out)
+
+
 def golden_wanet():
     """GridGenerator (networks/models.py:344-385), the WaNet warp (train_generator_wanet.py:151-157) with gradients,
     and two alternated WaNet steps (:132-237) through the reference modules (CIFAR-10 shape, no augmentation)."""
@@ -977,5 +1044,6 @@ if __name__ == "__main__":
     golden_eval_victim()
     golden_wanet()
     golden_wanet_trajectory()
+    golden_victim_wanet()
     golden_end_metric()
     golden_config()

@@ -1,0 +1,163 @@
+"""End-metric parity (the acceptance criterion north_star ends on): clean accuracy / backdoor benign accuracy /
+attack success rate of the whole pipeline -- train_clean_classifier -> train_generator -> train_victim -> eval.py --
+against the same pipeline driven through the REFERENCE's nn.Modules on the CPU (tests/golden/end_metric.npz, made by
+tests/golden/make_golden.py::golden_end_metric from /root/reference in the build container).
+
+Both sides see the same bytes (combat_amd.data.synthetic_structured: a learnable class-prototype set; real CIFAR-10 is
+not in the image) and the same random draws: the golden records every epoch permutation, num_bd, blur sigma and the
+poisoned index set, and this test replays the repo's own train() / eval() functions of the four entry scripts on them
+(the loaders' order and the two RNG draw sites are injected; everything else -- the steps, the evaluation loops, the
+keep-best checkpoint logic, checkpoint files handed from script to script -- runs as shipped, --post_transform_option
+no_use because the augmentation library is absent on the reference side).
+
+Tolerance: |delta| <= 0.5 percentage points on eval.py's three numbers (reference eval.py:108-152), as north_star
+states it.  The per-epoch counters of every stage are printed and bounded more loosely (they include epochs in the
+middle of training, where accuracies move by tens of points per epoch)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class NullWriter:
+    def add_scalars(self, *a, **k):
+        pass
+
+    def add_image(self, *a, **k):
+        pass
+
+
+def test_end_metrics_match_the_reference_pipeline(golden, tmp_path, monkeypatch):
+    import config
+    import eval as eval_script
+    import train_clean_classifier as tcc
+    import train_generator as tg
+    import train_victim as tv
+    from combat_amd import nets, step as step_mod, trigger
+    from combat_amd.data import ArrayLoader, synthetic_structured
+
+    g = golden("end_metric")
+    n_train, n_test, bs = int(g["cfg/n_train"]), int(g["cfg/n_test"]), int(g["cfg/bs"])
+    ea, eb, ec = int(g["cfg/epochs_a"]), int(g["cfg/epochs_b"]), int(g["cfg/epochs_c"])
+    s_clean, s_netc, s_netg, s_victim = (int(v) for v in g["cfg/seeds"])
+    signal, noise_rate = float(g["cfg/signal"]), float(g["cfg/noise_rate"])
+    xtr, ytr = synthetic_structured(n_train, int(g["cfg/seed_train"]), signal=signal)
+    xte, yte = synthetic_structured(n_test, int(g["cfg/seed_test"]), signal=signal)
+    assert int(xtr.astype(np.int64).sum()) == int(g["data/train_sum"]) and int(xte.astype(np.int64).sum()) == int(g["data/test_sum"])
+
+    opt = config.get_arguments().parse_args([
+        "--dataset", "cifar10", "--bs", str(bs), "--post_transform_option", "no_use", "--noise_rate", str(noise_rate),
+        "--checkpoints", str(tmp_path), "--log_interval", "1000", "--lr_C", str(float(g["cfg/lr"])),
+        "--lr_G", str(float(g["cfg/lr"])), "--lr_clean", str(float(g["cfg/lr"]))])
+    nets.configure_dataset(opt)
+    opt.device = "cuda"
+
+    class ReplayLoader(ArrayLoader):
+        """ArrayLoader whose epoch permutations are the recorded ones."""
+
+        def __init__(self, perms, *a, **k):
+            super().__init__(*a, **k)
+            self.perms = perms
+
+        def epoch_order(self, epoch):
+            return torch.from_numpy(np.asarray(self.perms[epoch]).astype(np.int64))
+
+    sig = {"q": iter(())}
+    monkeypatch.setattr(trigger, "sample_sigma", lambda *a, **k: float(next(sig["q"])))
+    test_dl = ArrayLoader(xte, yte, bs, False)
+    report = {}
+
+    def ckpt(stage):
+        opt.ckpt_folder = os.path.join(str(tmp_path), stage)
+        os.makedirs(opt.ckpt_folder, exist_ok=True)
+        opt.ckpt_path = os.path.join(opt.ckpt_folder, stage + ".pth.tar")
+        return opt.ckpt_path
+
+    # ---- A: train_clean_classifier.py
+    path_a = ckpt("clean")
+    torch.manual_seed(s_clean)
+    netA, optA, schA = tcc.get_model(opt)
+    dl = ReplayLoader(g["A/perm"], xtr, ytr, bs, True)
+    best, correct_a = 0.0, []
+    for ep in range(ea):
+        tcc.train(netA, optA, schA, dl, NullWriter(), ep, opt)
+        best = tcc.eval(netA, optA, schA, test_dl, best, NullWriter(), ep, opt)
+        netA.eval()
+        with torch.no_grad():
+            correct_a.append(sum(int((netA(x.cuda()).argmax(1).cpu() == t).sum()) for x, t in test_dl))
+    report["A clean correct / epoch"] = (correct_a, g["A/correct"].tolist())
+
+    # ---- B: train_generator.py
+    path_b = ckpt("generator")
+    torch.manual_seed(s_netc)
+    netC = nets.default_classifier(opt).to(opt.device)
+    torch.manual_seed(s_netg)
+    netG = nets.UnetGenerator(opt).to(opt.device)
+    torch.manual_seed(3)
+    netF = nets.FrequencyModel(num_classes=2, n_input=3, input_size=32).to(opt.device).eval()   # (metric only; no draw)
+    clean_model = nets.default_classifier(opt).to(opt.device)
+    clean_model.load_state_dict(torch.load(path_a, map_location=opt.device, weights_only=True)["netC"])
+    clean_model.eval()
+    sgd = lambda m: torch.optim.SGD(m.parameters(), float(g["cfg/lr"]), momentum=0.9, weight_decay=5e-4, nesterov=True)
+    sch = lambda o: torch.optim.lr_scheduler.MultiStepLR(o, [100, 150], 0.1)
+    optC, optG = sgd(netC), sgd(netG)
+    schC, schG = sch(optC), sch(optG)
+    draws = iter(zip(g["B/num_bd"].tolist(), g["B/sigma_c"].tolist(), g["B/sigma_g"].tolist()))
+    monkeypatch.setattr(step_mod.AlternatedStep, "_draw",
+                        lambda self, t, bt: step_mod.StepRandomness(*[f(v) for f, v in zip((int, float, float), next(draws))], [None] * 5))
+    dl = ReplayLoader(g["B/perm"], xtr, ytr, bs, True)
+    bests = (0.0,) * 6
+    ev_b = {"clean": [], "bd": []}
+    for ep in range(eb):
+        tg.train(netC, optC, schC, netG, optG, schG, netF, clean_model, dl, NullWriter(), ep, opt)
+        sig["q"] = iter(g["B/eval_sigma"][ep].tolist())
+        before = bests
+        bests = tg.eval(netC, optC, schC, netG, optG, schG, netF, clean_model, test_dl, *bests, NullWriter(), ep, opt)
+        ev_b["saved" if bests != before else "kept"] = ep
+    report["B best (clean acc, bd acc)"] = (bests[:2], None)
+    sdB = torch.load(path_b, map_location=opt.device, weights_only=True)
+    report["B saved epoch"] = (int(sdB["epoch_current"]), int(g["B/best_epoch"]))
+
+    # ---- C: train_victim.py
+    path_c = ckpt("victim")
+    torch.manual_seed(s_victim)
+    netV = nets.default_classifier(opt).to(opt.device)
+    optV = sgd(netV)
+    schV = sch(optV)
+    netGv = nets.UnetGenerator(opt).to(opt.device)
+    netGv.load_state_dict(sdB["netG"])
+    netGv.eval()
+    netGv.requires_grad_(False)
+    dl = ReplayLoader(g["C/perm"], xtr, ytr, bs, True, poisoned=g["C/poisoned"])
+    train_sig = iter(g["C/sigma"].tolist())
+    best_c = best_b = 0.0
+    for ep in range(ec):
+        sig["q"] = train_sig
+        tv.train(netV, optV, schV, netGv, dl, NullWriter(), ep, opt)
+        sig["q"] = iter(g["C/eval_sigma"][ep].tolist())
+        best_c, best_b = tv.eval(netV, optV, schV, netGv, test_dl, best_c, best_b, NullWriter(), ep, opt)
+    sdC = torch.load(path_c, map_location=opt.device, weights_only=True)
+    report["C saved epoch"] = (int(sdC["epoch_current"]), int(g["C/best_epoch"]))
+    report["C best clean acc"] = (best_c, float(g["C/eval_clean"].max()) * 100.0 / n_test)
+
+    # ---- D: eval.py on the victim's checkpoint
+    netD = nets.default_classifier(opt).to(opt.device)
+    netD.load_state_dict(sdC["netC"])
+    netD.eval()
+    sig["q"] = iter(g["D/eval_sigma"].tolist())
+    acc_clean, acc_ba, acc_asr = eval_script.eval(netD, netGv, test_dl, NullWriter(), opt)
+    bd_n = int(g["D/bd_n"])
+    ref = (int(g["D/clean"]) * 100.0 / n_test, int(g["D/bd_ba"]) * 100.0 / bd_n, int(g["D/bd_asr"]) * 100.0 / bd_n)
+    report["D clean acc / Bd BA / Bd ASR"] = ((acc_clean, acc_ba, acc_asr), ref)
+    for k, v in report.items():
+        print("end metric | %-32s ours %s   reference %s" % (k, v[0], v[1]))
+    for ours, theirs, name in zip((acc_clean, acc_ba, acc_asr), ref, ("clean acc", "Bd BA", "Bd ASR")):
+        assert abs(ours - theirs) <= 0.5, (name, ours, theirs)
+    assert abs(correct_a[-1] - int(g["A/correct"][-1])) * 100.0 / n_test <= 1.0

@@ -550,34 +550,62 @@ def test_backward_plans_do_not_share_weight_gradient_scratch(mods):
 
 def test_plan_replay_in_c_equals_python_replay(mods):
     """combat_plan_run (csrc/plan.cpp: the launch list walked in C, hand-off events reused) against the Python replay
-    of the same plans: five alternated steps from identical states must leave BIT-identical parameters, momentum,
-    running statistics and metric sums, with the auxiliary weight-gradient queue in play and in line (serial)."""
-    engine, step_mod = mods["engine"], mods["step"]
+    of the same plans.  Deterministic plans (the eval-mode forward: no atomics anywhere) must give BIT-identical
+    tensors; one whole alternated step from identical states -- whose weight gradients of the stride-2 / 1x1 / 3-channel
+    layers use fp32 atomics, so two replays of EITHER kind differ in the last bits -- must agree as closely as two
+    Python replays agree with each other (and to 1e-5), with the auxiliary weight-gradient queue in play and in line."""
+    engine, step_mod, nets, ops = mods["engine"], mods["step"], mods["nets"], mods["ops"]
     opt = Opt()
+    # ---- deterministic plan: bit-identical
+    m = seeded(nets.PreActResNet18, 0).cuda().eval()
+    eng = m._net_engine()
+    eng.refresh()
+    x, t = bench_batch(0, 32)
+    slot = eng.slot("creplay", 32, 32)
+    ops.image_to_c8(x.cuda(), eng.input(slot))
+    eng.head_bufs(slot)["targets"].copy_(t.cuda())
+    plan = eng.forward_plan(slot, False)
+    outs = []
+    for compiled in (False, True, True):
+        engine.Plan.compiled = compiled
+        try:
+            plan.run()
+            torch.cuda.synchronize()
+        finally:
+            engine.Plan.compiled = True
+        outs.append({k: v.clone() for k, v in slot.bufs.items() if v.dtype in (bf16, torch.float32) and k != "loss"})
+    assert plan._cplan and len(plan._prog_nomark) == 1 and plan._prog_nomark[0][0] == "c"   # one foreign call
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[1][k], outs[2][k]), k
 
+    # ---- one whole step
     def run(compiled, serial):
         engine.Plan.compiled = compiled
         engine.Plan.serial = serial
         try:
-            netc, clean, netg, netf = (m.cuda() for m in _build(mods, (0, 1, 2, 3)))
+            netc, clean, netg, netf = (mm.cuda() for mm in _build(mods, (0, 1, 2, 3)))
             clean.eval()
             st = step_mod.AlternatedStep(netc, netg, clean, netf, opt)
             st.serial = serial
-            for i in range(5):
-                x, t = bench_batch(i, 32)
-                st.run(x.cuda(), t, step_mod.StepRandomness(3 if i != 2 else 0, 0.4, 0.7, [None] * 5))
+            xb, tb = bench_batch(1, 32)
+            st.run(xb.cuda(), tb, step_mod.StepRandomness(3, 0.4, 0.7, [None] * 5))
             torch.cuda.synchronize()
-            state = {k: v.detach().clone() for m in (netc, netg) for k, v in m.state_dict().items()}
-            return state, st.eC.fp.mom.clone(), st.eG.fp.mom.clone(), st.read_metrics()
+            state = {k: v.detach().float().clone() for mm in (netc, netg) for k, v in mm.state_dict().items()}
+            return state, st.read_metrics()
         finally:
             engine.Plan.compiled, engine.Plan.serial = True, False
 
+    def dist(a, b):
+        return max(rel_l2(a[0][k].cpu(), b[0][k].cpu()) for k in a[0] if a[0][k].numel() > 1)
+
     for serial in (False, True):
-        ref, got = run(False, serial), run(True, serial)
-        for k in ref[0]:
-            assert torch.equal(ref[0][k], got[0][k]), (serial, k)
-        assert torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2])
-        assert ref[3] == got[3], (ref[3], got[3])
+        py1, py2, c1 = run(False, serial), run(False, serial), run(True, serial)
+        noise = dist(py1, py2)
+        assert dist(py1, c1) <= max(3 * noise, 1e-7) and dist(py1, c1) < 1e-5, (serial, noise, dist(py1, c1))
+        for k in ("clean_correct", "bd_correct", "train_correct", "clean_model_correct"):
+            assert py1[1][k] == c1[1][k]
+        for k in ("loss_c_sum", "loss_ce_sum", "clean_model_loss_sum", "loss_l2_sum"):
+            assert abs(py1[1][k] - c1[1][k]) <= 1e-5 * max(1.0, abs(py1[1][k])), (k, py1[1][k], c1[1][k])
 
 
 def test_plan_replay_reports_the_failing_call(mods):
@@ -686,11 +714,15 @@ def test_trajectory_vs_reference_trace(mods, golden, name, steps):
         assert abs(o.sum() - r.sum()) <= max(0.015 * steps * b, 8), (name, k, o.sum(), r.sum())
 
 
-def test_alternated_step_celeba_shape_resnet18(mods):
+@pytest.mark.parametrize("b", [8, 128])
+def test_alternated_step_celeba_shape_resnet18(mods, b):
     """BASELINE config 4's shape (CelebA: 3 x 64 x 64, 8 classes, ResNet18 surrogate and clean model, UNet at
-    64 x 64): one alternated step against the CPU oracle driven with the bf16-emulating networks.  Phase C
-    from the identical start state (loss, gradient norm, running statistics, parameter update); Phase G's
-    consumed values as bounds (netC differs by then between two bf16 realisations, as in the CIFAR test)."""
+    64 x 64), at a toy batch and at the configuration's own per-GPU batch of 128 (where DMA-tile thresholds, split
+    reductions and the statistics stage-1 launches take other branches): one alternated step against the CPU oracle
+    driven with the bf16-emulating networks, with the CIFAR test's method and tolerances -- Phase C from the identical
+    start state (loss 1e-2, gradient norm 3e-2, running statistics 1e-2, optimiser identity 1e-6), Phase G from the
+    engine's own post-Phase-C classifier with the generator emulation teacher-forced (losses 1e-2 * max(1, |ref|),
+    loss_l2 1e-3, counters +-1, generator gradient 5e-2)."""
     from oracle import combat_oracle as O
     step_mod, nets = mods["step"], mods["nets"]
     mk = lambda: nets.ResNet18(num_classes=8, input_size=64)
@@ -698,11 +730,11 @@ def test_alternated_step_celeba_shape_resnet18(mods):
     netg = seeded(lambda: nets.UnetGenerator(None), 13)
     netf = seeded(lambda: nets.FrequencyModel(2, 3, 64), 14).eval()
     oc, ok, og, of = (_oracle_state(m) for m in (netc, clean, netg, netf))
-    old_c = _oracle_state(netc)
-    b = 8
+    old_c, old_g = _oracle_state(netc), _oracle_state(netg)
     gen = torch.Generator().manual_seed(5)
     x = ((torch.randint(0, 256, (b, 3, 64, 64), generator=gen, dtype=torch.uint8).float() / 255) - 0.5) / 0.5
-    t = torch.tensor([0, 3, 0, 7, 0, 1, 0, 5])
+    t = torch.randint(0, 8, (b,), generator=gen)
+    t[::2][:4] = 0
     nb, sc, sg = 2, 0.6, 0.9
     cfg = O.StepConfig(num_classes=8, classifier="resnet18")
     bufs_c, bufs_g = [None] * len(O.trainable_names(oc)), [None] * len(O.trainable_names(og))
@@ -717,8 +749,11 @@ def test_alternated_step_celeba_shape_resnet18(mods):
     st.run(x.cuda(), t, step_mod.StepRandomness(nb, sc, sg, [None] * 5))
     torch.cuda.synchronize()
     m = st.read_metrics()
+    assert all(np.isfinite(v) for v in m.values())
     tol = lambda r: 1e-2 * max(1.0, abs(r))
+    # ---------------- Phase C (identical start state)
     assert abs(m["loss_c_sum"] - ref["loss_c"]) < tol(ref["loss_c"])
+    assert abs(m["clean_model_correct"] - ref["clean_model_correct"]) <= 1
     gn_c = float(st.eC.fp.grad.double().norm())
     assert abs(gn_c - ref["gnorm_c"]) < 3e-2 * ref["gnorm_c"], (gn_c, ref["gnorm_c"])
     num = den = 0.0
@@ -727,16 +762,42 @@ def test_alternated_step_celeba_shape_resnet18(mods):
         d_our = (netc.state_dict()[k].detach().cpu() - old_c[k]).double()
         num += float(((d_our - d_ref) ** 2).sum())
         den += float((d_ref ** 2).sum())
-    assert (num / den) ** 0.5 < 0.35, (num / den) ** 0.5
+    assert (num / den) ** 0.5 < 0.35, (num / den) ** 0.5      # bound only (mask flips); wiring is pinned by the module tests
     for k, v in netc.state_dict().items():
         if "running_mean" in k or "running_var" in k:
             assert rel_l2(v, oc[k]) < 1e-2, k
-    assert abs(m["loss_l2_sum"] - ref["loss_l2"]) < 2e-2 * ref["loss_l2"] + 1e-6
-    assert abs(m["loss_ce_sum"] - ref["loss_ce"]) < 0.15 * max(1.0, abs(ref["loss_ce"]))
-    assert abs(m["clean_model_loss_sum"] - ref["clean_model_loss"]) < 0.05 * max(1.0, abs(ref["clean_model_loss"]))
-    gn_g = float(st.eG.fp.grad.double().norm())
-    assert 0.5 * ref["gnorm_g"] < gn_g < 2.0 * ref["gnorm_g"], (gn_g, ref["gnorm_g"])
-    assert all(np.isfinite(v) for v in m.values())
+    fp = st.eC.fp
+    for k in ("conv1.weight", "layer2.0.bn1.bias", "layer4.1.conv2.weight", "linear.bias"):
+        gk = fp.logical(fp.grad, k).cpu()
+        exp = old_c[k] - 1e-2 * 1.9 * (gk + 5e-4 * old_c[k])
+        assert rel_l2(netc.state_dict()[k].detach().cpu(), exp) < 1e-6, k
+    # ---------------- Phase G (from the engine's post-Phase-C state)
+    oc2 = {k: v.detach().cpu().clone() for k, v in netc.state_dict().items()}
+    names_g = O.trainable_names(old_g)
+    pg = {k: v.clone().requires_grad_(k in names_g) for k, v in old_g.items()}
+    keys = ["t." + n for n, *_ in nets.UNET_LAYERS] + ["up0", "up1", "up2", "up3", "noise"]
+    noise = E.unet_forward_emu(pg, x, force=stored(st.sG, keys, 3))
+    ibd = O.trigger_mix(x, noise, 0.08, 0.65, sg)
+    assert float((st.bd.cpu() - ibd.detach()).abs().max()) < 3e-5
+    bd_t = torch.zeros_like(t)
+    leaf = ibd.detach().clone().requires_grad_(True)
+    pred_bd = E.resnet_forward_emu(oc2, leaf, False)
+    cm_pred = E.resnet_forward_emu(ok, leaf, False)
+    loss_ce, cm_loss = F.cross_entropy(pred_bd, bd_t), F.cross_entropy(cm_pred, t)
+    assert abs(m["loss_ce_sum"] - float(loss_ce.detach())) < tol(float(loss_ce.detach())), (m["loss_ce_sum"], float(loss_ce.detach()))
+    assert abs(m["clean_model_loss_sum"] - float(cm_loss.detach())) < tol(float(cm_loss.detach()))
+    l2 = float(F.mse_loss(ibd.detach(), x))
+    assert abs(m["loss_l2_sum"] - l2) < 1e-3 * l2 + 1e-7
+    assert abs(m["loss_grad_l2_sum"] - ref["loss_grad_l2"]) < 5e-2 * ref["loss_grad_l2"] + 1e-6
+    assert abs(m["bd_correct"] - int((pred_bd.argmax(1) == bd_t).sum())) <= 1
+    assert abs(m["clean_model_bd_ba"] - int((cm_pred.argmax(1) == t).sum())) <= 1
+    assert abs(m["clean_model_bd_asr"] - int((cm_pred.argmax(1) == bd_t).sum())) <= 1
+    (d_bd,) = torch.autograd.grad(loss_ce + 0.8 * cm_loss, leaf)
+    assert rel_l2((st.d_bd + st.d_bd2).cpu(), d_bd) < 0.25            # un-forced classifiers: mask-flip bound
+    total = (ibd * (st.d_bd + st.d_bd2).cpu()).sum() + 0.02 * F.mse_loss(ibd, x)
+    gr = torch.autograd.grad(total, [pg[k] for k in names_g], allow_unused=True)
+    gr = torch.cat([(torch.zeros_like(pg[k]) if a is None else a).reshape(-1) for k, a in zip(names_g, gr)])
+    assert rel_l2(flat_grads(st.eG.fp, names_g), gr) < 5e-2    # teacher-forced: pins trigger bwd + UNet bwd at 64 x 64
 
 
 def test_alternated_step_runs_with_sampled_randomness_and_empty_poison(mods):

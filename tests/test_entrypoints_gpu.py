@@ -38,6 +38,8 @@ def test_reference_workflow_on_synthetic_data(tmp_path):
                        "best_clean_acc", "best_bd_acc", "best_F_acc", "best_clean_model_acc", "best_clean_model_bd_ba",
                        "best_clean_model_bd_asr", "epoch_current"}
     assert len(sd["netG"]) == 32 and len(sd["netC"]) == 102
+    imgs = os.path.join(cwd, "ckpt", "train_generator_clean", "cifar10", "log_dir", "images")     # :310-315, epoch 0
+    assert (os.path.isdir(imgs) and any(f.endswith(".ppm") for f in os.listdir(imgs))) or "tensorboard" in sys.modules
     mom = sd["optimizerG"]["state"]
     assert len(mom) == 32 and all("momentum_buffer" in v for v in mom.values())
     assert all(torch.isfinite(v).all() for v in sd["netG"].values())
@@ -100,6 +102,25 @@ def test_wanet_workflow_on_synthetic_data(tmp_path):
     out = run("train_generator_wanet.py", "--saving_prefix", "train_generator_wanet", "--load_checkpoint_clean", "classifier_clean",
               "--n_iters", "2", "--continue_training", cwd=cwd)
     assert "Continue training!!" in out
+    # the rest of the WaNet pipeline (reference train_victim_wanet.py): victim on warped poisoned images, checkpoint
+    # under <prefix>_clean/ with the extra grid_rescale key (:199, :241-243), image grid logged every epoch (:136)
+    out = run("train_victim_wanet.py", "--saving_prefix", "train_victim_wanet", "--load_checkpoint", "train_generator_wanet_clean",
+              "--n_iters", "1", "--grid_rescale", "0.15", cwd=cwd)
+    assert "Bd Acc:" in out
+    vic = os.path.join(cwd, "ckpt", "train_victim_wanet_clean", "cifar10", "cifar10_train_victim_wanet_clean.pth.tar")
+    sdv = torch.load(vic, map_location="cpu", weights_only=True)
+    assert set(sdv) == {"netC", "schedulerC", "optimizerC", "netG", "best_clean_acc", "best_bd_acc", "epoch_current", "grid_rescale"}
+    assert len(sdv["netG"]) == 20 and len(sdv["netC"]) == 102
+    imgs = os.path.join(cwd, "ckpt", "train_victim_wanet_clean", "cifar10", "log_dir", "images")
+    assert os.path.isdir(imgs) and any(f.endswith(".ppm") for f in os.listdir(imgs)) or "tensorboard" in sys.modules
+    # train_victim.py refuses the WaNet generator by name; eval.py accepts it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_victim.py"), "--synthetic", "--synthetic_size", "256", "--bs", "64",
+                        "--checkpoints", os.path.join(cwd, "ckpt"), "--load_checkpoint", "train_generator_wanet_clean", "--n_iters", "1"],
+                       cwd=cwd, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "train_victim_wanet.py" in (r.stdout + r.stderr)
+    out = run("eval.py", "--saving_prefix", "train_generator_wanet", "--load_checkpoint_clean", "train_victim_wanet_clean",
+              "--load_checkpoint", "train_generator_wanet_clean", cwd=cwd)
+    assert "Bd ASR:" in out
 
 
 def test_wanet_celeba_workflow_on_synthetic_data(tmp_path):
@@ -154,6 +175,31 @@ def test_data_parallel_step_two_ranks_one_gpu(tmp_path):
         assert res["gradC_sum_vs_singles"] < 1e-5, res
         assert res["paramC_update_vs_mean_grad"] < 1e-6, res
         assert res["gradG_identical_across_ranks"] and res["replicas_bit_identical_after_2_steps"] and res["finite"], res
+
+
+def test_rccl_streams_beside_the_step_on_one_gpu():
+    """The `nccl` backend (= RCCL) itself, on the one GPU of the box: a fresh process creates the world-size-1 group
+    before any other GPU work, then runs 20 alternated steps whose bucketed gradient all-reduces are really issued
+    (COMBAT_FORCE_ALLREDUCE) -- RCCL's internal streams and events beside the step's three queues, the constellation
+    DESIGN.md section 5 "Schedule" measured a launch-blocking cliff for.  A one-rank sum is the identity: after one step
+    the state must equal the run without a group as closely as two such runs equal each other (fp32 atomics in a few
+    weight gradients: <= 1e-5), same counters; and the 20-step time must be within 5 % of it (+ 0.1 ms of timer noise)."""
+    import json
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "COMBAT_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_single.py"), str(port)], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("rccl world-1:", out)
+    assert out["backend"] == "nccl" and out["finite"] and out["counters_equal"], out
+    assert out["one_step_delta"] <= max(3 * out["one_step_noise"], 1e-7) and out["one_step_delta"] < 1e-5, out
+    assert out["ms_with_rccl"] <= 1.05 * out["ms_without"] + 0.1, out
 
 
 def test_bench_spawns_its_own_ranks(tmp_path):

@@ -534,3 +534,61 @@ def test_wanet_trajectory_first_steps(golden):
             assert abs(r[k] - ref) < 2e-4 * max(1.0, abs(ref)) + 1e-7, (s, k, r[k], ref)
         for k in ("clean_correct", "bd_correct", "f_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr"):
             assert r[k] == int(g["trace/" + k][s]), (s, k)
+
+
+def wanet_victim_nets(g):
+    """(netc, netg) of tests/golden/victim_wanet.npz: the mirror modules under the recorded seeds, BatchNorm buffers
+    and generator head randomised by the same calls as make_golden.py::golden_victim_wanet."""
+    from combat_amd import nets
+
+    class WOpt:
+        s = 2
+
+    s_c, s_g = (int(v) for v in g["seeds"])
+    torch.manual_seed(s_c)
+    netc = randomize_bn_buffers(nets.PreActResNet18(), int(g["bn_seed"]))
+    torch.manual_seed(s_g)
+    netg = nets.GridGenerator(WOpt()).eval()
+    h1, h2, h3 = (int(v) for v in g["head_seeds"])
+    with torch.no_grad():
+        netg.fc1.bias.normal_(0, 1.0, generator=torch.Generator().manual_seed(h1))
+        netg.fc2.weight.normal_(0, 0.5, generator=torch.Generator().manual_seed(h2))
+        netg.fc2.bias.normal_(0, 0.5, generator=torch.Generator().manual_seed(h3))
+    return netc, netg
+
+
+def test_wanet_victim_step_and_eval_match_the_reference_modules(golden):
+    """oracle.victim_step / oracle.eval_batch with cfg.trigger == "wanet" against one training batch and two evaluation
+    batches of train_victim_wanet.py (:72-112 with the D3 intent, :150-181) recorded from the reference's PreActResNet18
+    and GridGenerator through its own F.upsample / F.grid_sample calls (make_golden.py::golden_victim_wanet)."""
+    from oracle import combat_oracle as O
+    g = golden("victim_wanet")
+    netc, netg = wanet_victim_nets(g)
+    check_summary(g, "netg", [(k, v) for k, v in netg.state_dict().items() if k.startswith("fc")], 1e-6)
+    sd = lambda m: {k: v.detach().clone() for k, v in m.state_dict().items()}
+    oc, og = sd(netc), sd(netg)
+    cfg = O.StepConfig(trigger="wanet")
+    s_img, s_lab = (int(v) for v in g["eval/seeds"])
+    for s, b in enumerate(int(v) for v in g["eval/batch"]):
+        x = synth_images(b, 32, s_img + s)
+        t = torch.randint(0, 10, (b,), generator=torch.Generator().manual_seed(s_lab + s))
+        r = O.eval_batch(oc, og, x, t, 0.5, cfg)
+        for k in ("clean_n", "clean_correct", "bd_n", "bd_correct", "bd_ba"):
+            assert r[k] == int(g["eval/" + k][s]), (s, k, r[k], int(g["eval/" + k][s]))
+    vi, vl = (int(v) for v in g["victim/seeds"])
+    x = synth_images(48, 32, vi)
+    t = torch.randint(0, 10, (48,), generator=torch.Generator().manual_seed(vl))
+    t[:6] = 0
+    pz = torch.from_numpy(g["victim/poisoned"])
+    ibd, _ = O.wanet_warp(x[pz], O.grid_generator_forward(og, x[pz]), cfg.grid_rescale)
+    assert float((ibd - torch.from_numpy(g["victim/inputs_bd"])).abs().max()) < 1e-5
+    names = O.trainable_names(oc)
+    r = O.victim_step(oc, [None] * len(names), x, t, cfg, netg=og, poisoned=pz)
+    assert abs(r["loss"] - float(g["victim/loss"])) < 1e-5 and r["correct"] == int(g["victim/correct"]) and r["num_bd"] == 3
+    assert abs(r["gnorm"] - float(g["victim/gnorm"])) < 1e-4 * float(g["victim/gnorm"])
+    num = den = 0.0
+    for k, v in zip(names, r["grads"]):
+        d = v.double().flatten()[g["victim/gp/%s/idx" % k]].numpy() - g["victim/gp/%s/val" % k]
+        num, den = num + float((d ** 2).sum()), den + float((g["victim/gp/%s/val" % k] ** 2).sum())
+    assert (num / den) ** 0.5 < 5e-3, (num / den) ** 0.5      # (same amplification of 1e-6 image differences as the UNet victim step)
+    check_summary(g, "victim/after", oc.items(), 1e-4)

@@ -30,6 +30,18 @@ for i in range(N):
     host += time.perf_counter() - h0
 t_host_done = time.perf_counter()
 torch.cuda.synchronize()
+if os.environ.get("QS_PARKED"):
+    # pure host cost of enqueueing a step: the device is parked behind a long spin kernel, so no call waits for it
+    # (a step is ~700 queue packets; three of them fit the queue)
+    for k in range(3):
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(2.0e9 * 0.04))
+        h0 = time.perf_counter()
+        for i in range(3):
+            st.run(*batches[i % 8])
+        h1 = time.perf_counter()
+        torch.cuda.synchronize()
+        print("host enqueue with the device parked: %.3f ms/step" % ((h1 - h0) / 3 * 1e3))
 from combat_amd.engine import Plan
 nd = getattr(Plan, "_ndelay", 0) / (N + 10)
 print("delay launches/step %.1f" % nd)

@@ -100,6 +100,7 @@ def main():
         tf_writer = SummaryWriter(log_dir=opt.log_dir)
     else:
         tf_writer = cdist.NullWriter()
+    train_dl.epoch = epoch_current      # a seeded, resumed run continues the sequence of epoch permutations
     for epoch in range(epoch_current, opt.n_iters):
         print("Epoch {}:".format(epoch + 1))
         t0 = time.perf_counter()
