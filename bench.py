@@ -51,7 +51,7 @@ TILE_NAMES = {1: "conv_gemm_kernel<128,128>", 2: "conv_gemm_kernel<128,64>", 3: 
               6: "conv3x3_halo1_kernel<256,64>", 7: "conv3x3_halo1_kernel<128,128>", 8: "conv3x3_halo1_kernel<128,64>",
               9: "conv3x3_halo_kernel<64,64>", 10: "conv3x3_dma_kernel<64>", 11: "conv3x3_dma_kernel<32>",
               12: "conv_gather_dma_kernel<64>", 13: "conv_gather_dma_kernel<32>", 14: "conv3x3_dma_kernel<64,256px>",
-              15: "conv_c8_kernel", 16: "conv3x3_dma_kernel<64,256px,w64>"}
+              15: "conv_c8_kernel", 16: "conv3x3_dma_kernel<64,256px,w64>", 17: "conv3x3_ws_kernel<64>"}
 
 
 def log(msg):
@@ -193,8 +193,12 @@ def roofline_from(prof):
             key = shape_key(a.H if a.mode == 0 else a.P, pc.c_real, pc.K, pc.R, pc.stride)
             kind = "fwd" if a.mode == 0 else "dgrad"
         else:
-            fl = wgrad_flops(a)
             key, kind = shape_key(a.H, a.c_real, a.k_real, a.R, a.stride), "wgrad"
+            if what.endswith(".reduce"):     # the deferred reduction of a weight gradient: time, no work, no launch of its own
+                if what.startswith("preact."):
+                    per_shape.setdefault(key, {}).setdefault(kind, [0.0, 0.0, 0])[1] += sec
+                continue
+            fl = wgrad_flops(a)
         if what.startswith("preact."):
             d = per_shape.setdefault(key, {}).setdefault(kind, [0.0, 0.0, 0])
             d[0] += fl

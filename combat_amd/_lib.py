@@ -47,6 +47,7 @@ class WgradArgs(C.Structure):
         ("pro_scale", c_vp), ("pro_shift", c_vp), ("pro_group_stride", c_i32), ("pro_act", c_i32),
         ("pro_slope", c_f32), ("split", c_i32),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
+        ("defer_reduce", c_i32), ("reserved", c_i32),
     ]
 
 
@@ -78,6 +79,7 @@ SIGNATURES = {
     "combat_conv_stats_layout": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(c_i32), C.POINTER(c_i32)]),
     "combat_conv_wgrad": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
     "combat_conv_wgrad_workspace_bytes": (c_i64, [C.POINTER(WgradArgs)]),
+    "combat_conv_wgrad_reduce": (C.c_int, [C.POINTER(WgradArgs), c_vp]),
     "combat_pack_weights": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32,
                                       c_i32, c_vp]),
     "combat_norm_finalize": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -134,6 +136,7 @@ SIGNATURES = {
     "combat_plan_destroy": (None, [c_vp]),
     "combat_plan_record": (C.c_int, [c_vp, c_i32]),
     "combat_plan_record_cancel": (C.c_int, []),
+    "combat_plan_set_after": (C.c_int, [c_vp, c_i32]),
     "combat_plan_size": (c_i32, [c_vp]),
     "combat_plan_run": (C.c_int, [c_vp, c_i32, c_i32, c_vp, C.POINTER(c_vp), c_i32]),
     "combat_plan_join": (C.c_int, [c_vp, c_vp, C.POINTER(c_vp), c_i32]),

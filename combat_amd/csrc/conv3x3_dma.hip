@@ -267,9 +267,20 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
 #pragma unroll
         for (int i = 0; i < T::FN; ++i) asm volatile("" : "+v"(fw[i]));
 #endif
-        __builtin_amdgcn_sched_barrier(0);
     };
-    auto mfma_frags = [&](const bf16x8_t (&fp)[T::FM], const bf16x8_t (&fw)[T::FN]) __attribute__((always_inline)) {
+    // with_reads: the FM + FN fragment reads issued just before (into the other register set) are spread one per
+    // MFMA gap -- an MFMA holds the SIMD's vector issue for 8 of its 16 cycles, so a read issued inside a gap is nearly
+    // free, while a block of reads in front of the MFMA block costs its full issue time (COMBAT_NO_INTERLEAVE: the
+    // block form, for A/B timing).  Measured (tools/conv_bench.py, back to back / cold): 64-channel tiles 14.6 -> 14.0 /
+    // 20.0 -> 19.3 us on the 128-channel 16 x 16 layer; 32-channel tiles (as many reads as MFMAs: nothing to hide
+    // them behind) 15.6 -> 16.3 us on the 512-channel 4 x 4 layer, so those keep the block form.
+    constexpr bool kInterleave = T::FM * T::FN > T::FM + T::FN;
+    auto mfma_frags = [&](const bf16x8_t (&fp)[T::FM], const bf16x8_t (&fw)[T::FN], bool with_reads) __attribute__((always_inline)) {
+#ifdef COMBAT_NO_INTERLEAVE
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        if (!kInterleave) __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int i = 0; i < T::FN; ++i)
 #pragma unroll
@@ -278,6 +289,19 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[i], fp[j], acc[i][j], 0, 0, 0);
 #else
                 acc[i][j][0] += (float)fw[i][0] * (float)fp[j][0];
+#endif
+#if !defined(COMBAT_NO_INTERLEAVE) && !defined(COMBAT_ABL_NOREAD) && !defined(COMBAT_ABL_NOMFMA)
+        if (with_reads && kInterleave) {
+            constexpr int NR = T::FM + T::FN, NM = T::FM * T::FN, NP = NR < NM ? NR : NM;
+#pragma unroll
+            for (int r = 0; r < NP; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read
+            }
+            if (NM > NP) __builtin_amdgcn_sched_group_barrier(0x008, NM - NP, 0);
+        }
+#else
+        (void)with_reads;
 #endif
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -339,6 +363,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     block_barrier();
     DSTAMP(1);
     read_frags(fpA, fwA, I0{}, I0{}, I0{});
+    __builtin_amdgcn_sched_barrier(0);
 
     auto chunk = [&](auto last_tag, auto hbuf_tag, int cc) __attribute__((always_inline)) {
         constexpr bool last = decltype(last_tag)::value;
@@ -350,7 +375,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         using TT = std::integral_constant<int, t>;                                                           \
         using TN = std::integral_constant<int, (t + 1) % 9>;                                                 \
         read_frags(fpB, fwB, TT{}, I1{}, HBUF{});                                                            \
-        mfma_frags(fpA, fwA);                                                                                \
+        mfma_frags(fpA, fwA, true);                                                                          \
         if (!(last && t == 8)) {                                                                             \
             constexpr int n_w = (last && t >= 7) ? 0 : ABL_DMA(WPW);                                         \
             constexpr int n_h = (!last && (t == 1 || t == 2)) ? ABL_DMA(HPW) : 0;                            \
@@ -361,10 +386,11 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
             else if (!last) issue_w(t + 3 - 9, cc + 1, t % 3);                                               \
             if (t == 0 && !last) issue_h(cc + 1, HNEXT::value);                                              \
             if (last && t == PF_T) epilogue_fetch();                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                               \
             if (t < 8) read_frags(fpA, fwA, TN{}, I0{}, HBUF{});                                             \
             else read_frags(fpA, fwA, TN{}, I0{}, HNEXT{});                                                  \
         }                                                                                                    \
-        mfma_frags(fpB, fwB);                                                                                \
+        mfma_frags(fpB, fwB, !(last && t == 8));                                                             \
     }
         COMBAT_DMA_POS(0) COMBAT_DMA_POS(1) COMBAT_DMA_POS(2) COMBAT_DMA_POS(3) COMBAT_DMA_POS(4)
         COMBAT_DMA_POS(5) COMBAT_DMA_POS(6) COMBAT_DMA_POS(7) COMBAT_DMA_POS(8)

@@ -23,6 +23,7 @@ long conv_gather_dma_workspace(const combat_conv_args *a);        // scratch byt
 int conv_wgrad3x3_try(const combat_wgrad_args *a, hipStream_t st);
 int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st);   // same, for inputs without a prologue
 long conv_wgrad3x3_dma_workspace(const combat_wgrad_args *a);             // scratch bytes it can use (0: not applicable)
+int conv_wgrad3x3_dma_reduce(const combat_wgrad_args *a, hipStream_t st);  // the reduction a defer_reduce launch left out
 
 template <int BM, int BN, int WGM_ = 0>
 struct TileCfg {

@@ -486,8 +486,7 @@ extern "C" int64_t combat_conv_wgrad_workspace_bytes(const combat_wgrad_args *a)
     return a && a->split >= 0 ? (int64_t)conv_wgrad3x3_dma_workspace(a) : 0;
 }
 
-extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
-    COMBAT_PLAN_HOOK(combat_conv_wgrad, a);
+static int validate_wgrad_args(const combat_wgrad_args *a) {
     if (!a || !a->src || !a->dy || !a->dw) return COMBAT_EINVAL;
     if (a->N <= 0 || a->H <= 0 || a->W <= 0 || a->P <= 0 || a->Q <= 0) return COMBAT_EINVAL;
     if (a->C < 8 || (a->C & 7) || a->K < 8 || (a->K & 7)) return COMBAT_EINVAL;
@@ -495,13 +494,25 @@ extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
     if (a->stride != 1 && a->stride != 2) return COMBAT_EINVAL;
     if (a->c_real <= 0 || a->c_real > a->C || a->k_real <= 0 || a->k_real > a->K) return COMBAT_EINVAL;
     if ((a->pro_scale == nullptr) != (a->pro_shift == nullptr)) return COMBAT_EINVAL;
+    if ((long)a->N * a->P * a->Q > 0x7fffffffL / 8) return COMBAT_EINVAL;
+    return COMBAT_OK;
+}
+
+extern "C" int combat_conv_wgrad_reduce(const combat_wgrad_args *a, void *stream) {
+    COMBAT_PLAN_HOOK(combat_conv_wgrad_reduce, a);
+    if (validate_wgrad_args(a) != COMBAT_OK) return COMBAT_EINVAL;
+    if (a->split < 0 || !a->defer_reduce) return COMBAT_OK;       // (the launch did its own reduction)
+    return conv_wgrad3x3_dma_reduce(a, as_stream(stream));
+}
+
+extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
+    COMBAT_PLAN_HOOK(combat_conv_wgrad, a);
+    if (validate_wgrad_args(a) != COMBAT_OK) return COMBAT_EINVAL;
     WgradParams p;
     p.a = *a;
     p.ws = nullptr;
     p.PQ = a->P * a->Q;
-    const long M = (long)a->N * p.PQ;
-    if (M > 0x7fffffffL / 8) return COMBAT_EINVAL;
-    p.M = (int)M;
+    p.M = (int)((long)a->N * p.PQ);
     p.ntaps = a->R * a->S;
     hipStream_t st = as_stream(stream);
     if (a->split >= 0) {   // split < 0 forces the generic kernel (tests)

@@ -19,6 +19,7 @@
 // is the first one's address ^ 64 -- and src channels 16 wave_c + [0,16), for all nine taps (72
 // accumulator registers).
 #include "conv_common.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -226,7 +227,9 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         constexpr int set = slot / SPS, imm = (slot % SPS) * XBYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) fx[ks] = join8(tr16d(xp[set][ks][0][tap] + imm), tr16d(xp[set][ks][1][tap] + imm));
+#ifdef COMBAT_NO_INTERLEAVE
         __builtin_amdgcn_sched_barrier(0);
+#endif
     };
     auto mfma_tap = [&](auto tap_tag, const bf16x8_t (&fk)[2][2], const bf16x8_t (&fx)[2]) __attribute__((always_inline)) {
         constexpr int tap = decltype(tap_tag)::value;
@@ -235,6 +238,17 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 acc[tap][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[ks][i], fx[ks], acc[tap][i], 0, 0, 0);
+#ifndef COMBAT_NO_INTERLEAVE
+        // the next tap's four transposing reads (issued just before, into the other register pair) go one per MFMA
+        // gap: an MFMA holds the SIMD's vector issue for 8 of its 16 cycles (conv3x3_dma.hip, mfma_frags)
+        if (tap < 8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     auto compute = [&](auto slot_tag, auto nslot_tag, bool ahead) __attribute__((always_inline)) {
@@ -256,6 +270,7 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
         (void)ahead;
         bf16x8_t fx0[2], fx1[2];
         x_frags(fx0, slot_tag, integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
 #define COMBAT_W3_TAP(t, cur, nxt)                                                   \
         if (t < 8) x_frags(nxt, slot_tag, integral_constant<int, (t < 8 ? t + 1 : 8)>{});  \
         mfma_tap(integral_constant<int, t>{}, fk, cur);
@@ -457,7 +472,8 @@ int pick_split(const combat_wgrad_args *a, const W3dParams &p, bool with_ws) {
     const int base = p.tiles_k * p.tiles_c;
     int split = a->split;
     if (split <= 0) {
-        const int by_cus = ((with_ws ? 128 : 256) + base - 1) / base;
+        static const int ws_wgs = getenv("COMBAT_WGRAD_WGS") ? atoi(getenv("COMBAT_WGRAD_WGS")) : 128;   // (experiments)
+        const int by_cus = ((with_ws ? ws_wgs : 256) + base - 1) / base;
         const int by_atomics = 164 / base > 0 ? 164 / base : 1;
         split = with_ws || by_cus < by_atomics ? by_cus : by_atomics;
         const int by_work = (p.ntiles + 3) / 4;
@@ -479,29 +495,24 @@ long conv_wgrad3x3_dma_workspace(const combat_wgrad_args *a) {
     return split > 1 ? (long)split * p.tiles_k * p.tiles_c * 9 * 4096 * 4 : 0;
 }
 
-// returns COMBAT_OK if launched, 1 if this kernel does not apply (caller falls back), <0 on error
-int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st) {
-    W3dParams p;
+namespace {
+// geometry, pixel ranges and workspace use of a launch: ONE place, so that the deferred reduction walks exactly the
+// slabs its kernel launch wrote
+bool w3d_plan(const combat_wgrad_args *a, W3dParams &p) {
     int smem;
-    if (!w3d_geometry(a, p, smem)) return 1;
+    if (!w3d_geometry(a, p, smem)) return false;
     const int base = p.tiles_k * p.tiles_c;
     int split = pick_split(a, p, true);
     const bool use_ws = split > 1 && a->workspace && a->workspace_bytes >= (long)split * base * 9 * 4096 * 4;
     if (!use_ws) split = pick_split(a, p, false);
     p.ws = use_ws ? reinterpret_cast<float *>(a->workspace) : nullptr;
-#ifdef COMBAT_STAMPS
-    p.stamps = g_stamps_wgrad_host;
-#else
-    p.stamps = nullptr;
-#endif
     p.per = (p.ntiles + split - 1) / split;
     p.split = (p.ntiles + p.per - 1) / p.per;
-    const int blocks = base * p.split;
-    int rc;
-    if (p.hpw == 2) rc = launch_w3d<2, 3>(p, blocks, st);        // 3 x 24 KB
-    else if (p.hpw == 3) rc = launch_w3d<3, 2>(p, blocks, st);   // 2 x 32 KB
-    else rc = launch_w3d<4, 2>(p, blocks, st);                   // 2 x 40 KB
-    if (rc != COMBAT_OK || !p.ws) return rc;
+    return true;
+}
+
+int launch_reduce(const combat_wgrad_args *a, const W3dParams &p, hipStream_t st) {
+    const int base = p.tiles_k * p.tiles_c;
     // enough workgroups to fill the chip; each group of ranges costs one fp32 atomic per element
     const long e4 = (long)base * 9 * 1024;
     int groups = (int)(512 / ((e4 + 255) / 256));
@@ -511,4 +522,30 @@ int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st) {
                        p.tiles_c, p.split, a->k_real, a->c_real);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
+}
+}  // namespace
+
+// returns COMBAT_OK if launched, 1 if this kernel does not apply (caller falls back), <0 on error
+int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st) {
+    W3dParams p;
+    if (!w3d_plan(a, p)) return 1;
+#ifdef COMBAT_STAMPS
+    p.stamps = g_stamps_wgrad_host;
+#else
+    p.stamps = nullptr;
+#endif
+    const int blocks = p.tiles_k * p.tiles_c * p.split;
+    int rc;
+    if (p.hpw == 2) rc = launch_w3d<2, 3>(p, blocks, st);        // 3 x 24 KB
+    else if (p.hpw == 3) rc = launch_w3d<3, 2>(p, blocks, st);   // 2 x 32 KB
+    else rc = launch_w3d<4, 2>(p, blocks, st);                   // 2 x 40 KB
+    if (rc != COMBAT_OK || !p.ws || a->defer_reduce) return rc;
+    return launch_reduce(a, p, st);
+}
+
+// the reduction a defer_reduce launch left out: COMBAT_OK (also when there is nothing to reduce), <0 on error
+int conv_wgrad3x3_dma_reduce(const combat_wgrad_args *a, hipStream_t st) {
+    W3dParams p;
+    if (!w3d_plan(a, p) || !p.ws) return COMBAT_OK;
+    return launch_reduce(a, p, st);
 }

@@ -18,9 +18,12 @@ struct combat_plan {
     struct Call {
         std::function<int(void *)> fn;
         int queue;
+        int after;        // index of an earlier call this one waits for (-1: none)
+        bool awaited;     // some later call waits for this one: record `done` behind it
     };
     std::vector<Call> calls;
     std::vector<hipEvent_t> handoff;   // one per call that runs on an auxiliary queue
+    std::vector<hipEvent_t> done;      // one per awaited call
     std::vector<hipEvent_t> join;      // one per auxiliary queue
     unsigned used = 0;                 // auxiliary queues with work not yet joined
     int failed = -1;                   // index of the call whose status combat_plan_run returned
@@ -41,8 +44,9 @@ bool armed() { return t_plan != nullptr; }
 int capture(std::function<int(void *)> call) {
     combat_plan *p = t_plan;
     t_plan = nullptr;   // one-shot: a captured call that itself calls entry points replays them normally
-    p->calls.push_back({std::move(call), t_queue});
+    p->calls.push_back({std::move(call), t_queue, -1, false});
     p->handoff.push_back(nullptr);
+    p->done.push_back(nullptr);
     return COMBAT_OK;
 }
 }  // namespace combat_plan_detail
@@ -55,6 +59,8 @@ extern "C" void combat_plan_destroy(combat_plan *p) {
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : p->join)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : p->done)
+        if (e) (void)hipEventDestroy(e);
     delete p;
 }
 
@@ -62,6 +68,13 @@ extern "C" int combat_plan_record(combat_plan *p, int32_t queue) {
     if (!p || t_plan) return COMBAT_EINVAL;
     t_plan = p;
     t_queue = queue;
+    return COMBAT_OK;
+}
+
+extern "C" int combat_plan_set_after(combat_plan *p, int32_t call_index) {
+    if (!p || p->calls.empty() || call_index < 0 || call_index >= (int32_t)p->calls.size() - 1) return COMBAT_EINVAL;
+    p->calls.back().after = call_index;
+    p->calls[call_index].awaited = true;
     return COMBAT_OK;
 }
 
@@ -80,18 +93,28 @@ extern "C" int combat_plan_run(combat_plan *p, int32_t begin, int32_t end, void 
     hipStream_t main_st = reinterpret_cast<hipStream_t>(stream);
     for (int32_t i = begin; i < end; ++i) {
         const combat_plan::Call &c = p->calls[i];
+        const bool on_aux = c.queue >= 0 && n_aux > 0;
+        void *const st_i = on_aux ? aux_streams[c.queue % n_aux] : stream;
+        // (in-line replay, n_aux == 0: stream order already gives every `after`)
+        if (c.after >= 0 && n_aux > 0 && p->done[c.after] &&
+            hipStreamWaitEvent(reinterpret_cast<hipStream_t>(st_i), p->done[c.after], 0) != hipSuccess)
+            return COMBAT_ELAUNCH;
         int rc;
-        if (c.queue >= 0 && n_aux > 0) {
-            const int q = c.queue % n_aux;
-            hipStream_t aux = reinterpret_cast<hipStream_t>(aux_streams[q]);
+        if (on_aux) {
+            hipStream_t aux = reinterpret_cast<hipStream_t>(st_i);
             hipEvent_t &ev = p->handoff[i];
             if (!ev && !(ev = new_event())) return COMBAT_ELAUNCH;
             // everything enqueued so far (the producers of this call's operands) happens-before it
             if (hipEventRecord(ev, main_st) != hipSuccess || hipStreamWaitEvent(aux, ev, 0) != hipSuccess) return COMBAT_ELAUNCH;
-            rc = c.fn(aux_streams[q]);
-            p->used |= 1u << q;
+            rc = c.fn(st_i);
+            p->used |= 1u << (c.queue % n_aux);
         } else {
             rc = c.fn(stream);
+        }
+        if (rc == COMBAT_OK && c.awaited && n_aux > 0) {
+            hipEvent_t &ev = p->done[i];
+            if (!ev && !(ev = new_event())) return COMBAT_ELAUNCH;
+            if (hipEventRecord(ev, reinterpret_cast<hipStream_t>(st_i)) != hipSuccess) return COMBAT_ELAUNCH;
         }
         if (rc != COMBAT_OK) {
             p->failed = i;

@@ -35,6 +35,16 @@ class Plan:
 
     serial = False   # True: auxiliary-stream calls run in line (kernel-level measurements: one kernel at a time)
     default_aux_queues = 1   # auxiliary queues a new plan deals its aux calls to (see aux_queues below)
+    flush_at_marks = False   # data parallel: deferred weight-gradient reductions are issued at every all-reduce mark
+    #                          (the gradients above a mark must be final there); otherwise all of them at the end of
+    #                          the plan, on its own stream, each behind its weight gradient only
+    # Deferred weight-gradient reductions (combat_wgrad_args.defer_reduce + Plan.flush_reduces) are OFF by default:
+    # measured on the alternated step (tools/quick_step.py, same box, same process order) 4.31 ms/step with every
+    # reduction right behind its kernel on the auxiliary queue, 4.45-4.51 with the reductions on the plan's own stream
+    # behind per-call events (private 19-MB slab regions or a ring of two: no difference; private regions WITHOUT
+    # deferral: 4.32, so it is not the slabs leaving the Infinity Cache) -- twenty event records between the auxiliary
+    # queue's kernels and twenty cross-queue waits cost more than the 8-us reductions they take off that queue.
+    defer_reduces = os.environ.get("COMBAT_DEFER_REDUCE", "0") == "1"
 
     def __init__(self, name: str):
         self.name = name
@@ -49,14 +59,28 @@ class Plan:
         self._ws = None
         self._cplan = None                # combat_plan* of the compiled form (built on first run)
         self._prog = None
+        self.after: Dict[int, int] = {}   # call index -> index of an earlier call it waits for (on whatever queue that ran)
+        self.pending_reduces: List[Tuple] = []   # (what, WgradArgs, index of its weight-gradient call)
 
-    def add(self, what: str, cfunc, *args, aux: bool = False) -> None:
+    def add(self, what: str, cfunc, *args, aux: bool = False, after: Optional[int] = None) -> None:
         """aux: the call's result is only consumed after the plan (weight gradients: by the optimiser /
-        all-reduce), so it may run on the auxiliary stream beside the calls that follow it."""
+        all-reduce), so it may run on the auxiliary stream beside the calls that follow it.
+        after: index of an earlier call (typically an aux one) this call must wait for."""
         self.calls.append((cfunc, args, what))
         self._prog = None
         if aux:
             self.aux[len(self.calls) - 1] = self.next_aux_queue()
+        if after is not None:
+            self.after[len(self.calls) - 1] = after
+
+    def flush_reduces(self) -> None:
+        """Issue the reductions of the weight gradients recorded with defer_reduce so far: on the plan's own stream,
+        each waiting for its weight-gradient launch only.  The auxiliary queue then holds a chain of weight-gradient
+        kernels instead of (kernel, reduction) pairs -- the reductions were 10 of every 40 us of what is the critical
+        path of both training backward passes -- and the reductions run while it works on the next layers."""
+        for what, a, ci in self.pending_reduces:
+            self.add(what, lib.combat_conv_wgrad_reduce, ctypes.byref(a), after=ci)
+        self.pending_reduces = []
 
     def next_aux_queue(self) -> int:
         """Queue the next aux call will be given (round-robin over `aux_queues`)."""
@@ -83,6 +107,8 @@ class Plan:
 
     def mark(self, grad_offset: int) -> None:
         """Every gradient at flat offset >= grad_offset is final once the calls recorded so far ran."""
+        if self.flush_at_marks or grad_offset == 0:
+            self.flush_reduces()
         self.marks[len(self.calls) - 1] = grad_offset
 
     compiled = os.environ.get("COMBAT_PLAN_PY", "0") != "1"   # False: replay every plan from Python (debugging / A-B timing)
@@ -99,6 +125,7 @@ class Plan:
         if not cp:
             raise CombatHipError("combat_plan_create failed")
         prog, names, begin = [], [], None
+        cindex = {}      # plan call index -> index inside the combat_plan
         for ci, (cfunc, args, what) in enumerate(self.calls):
             captured = False
             if getattr(cfunc, "argtypes", None) is not None:       # a ctypes entry point
@@ -111,13 +138,16 @@ class Plan:
                     raise CombatHipError("%s/%s: recording failed (%d)" % (self.name, what, rc))
             if captured:
                 names.append(what)
+                cindex[ci] = len(names) - 1
+                if ci in self.after:
+                    ops.check(lib.combat_plan_set_after(cp, cindex[self.after[ci]]), "combat_plan_set_after")
                 if begin is None:
                     begin = len(names) - 1
             else:
                 if begin is not None:
                     prog.append(("c", begin, len(names)))
                     begin = None
-                assert ci not in self.aux, "only C-ABI calls can run on an auxiliary queue"
+                assert ci not in self.aux and ci not in self.after, "only C-ABI calls can run on an auxiliary queue / wait for a call"
                 prog.append(("py", cfunc, args, what))
             if ci in self.marks:
                 if begin is not None:
@@ -193,7 +223,11 @@ class Plan:
         if self.aux and not Plan.serial:
             auxs = [_aux_stream(stream, k) for k in range(self.aux_queues)]
         used = set()
+        awaited = set(self.after.values()) if auxs else set()
+        done: Dict[int, torch.cuda.Event] = {}
         for ci, (cfunc, args, what) in enumerate(self.calls):
+            if auxs and ci in self.after and self.after[ci] in done:
+                (auxs[self.aux[ci]] if ci in self.aux else stream).wait_event(done[self.after[ci]])
             if prof is not None and cfunc is lib.combat_conv_gemm_pair:     # measured one kernel at a time
                 rc = 0
                 for sub, arg in zip(what.split("+"), args):
@@ -202,7 +236,8 @@ class Plan:
                     rc = rc or lib.combat_conv_gemm(arg, st)
                     e1.record(stream)
                     prof.append((self.name + "/" + sub, arg._obj, e0, e1))
-            elif prof is not None and (cfunc is lib.combat_conv_gemm or cfunc is lib.combat_conv_wgrad):
+            elif prof is not None and (cfunc is lib.combat_conv_gemm or cfunc is lib.combat_conv_wgrad or
+                                       cfunc is lib.combat_conv_wgrad_reduce):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 rc = cfunc(*args, st)
@@ -221,6 +256,9 @@ class Plan:
             if rc:
                 kind = {-1: "invalid shape/argument", -2: "HIP launch failed"}.get(rc, "status %d" % rc)
                 raise CombatHipError("%s/%s: %s" % (self.name, what, kind))
+            if ci in awaited:
+                done[ci] = torch.cuda.Event()
+                done[ci].record(auxs[self.aux[ci]] if ci in self.aux else stream)
             if on_mark is not None and ci in self.marks:
                 for q in used:   # the gradients above the mark include auxiliary-stream results
                     ev = torch.cuda.Event()
@@ -422,9 +460,17 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
     a.split = 0
     ws = _wgrad_workspace(src.device, plan.next_aux_queue() if aux else -1)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    need = int(lib.combat_conv_wgrad_workspace_bytes(ctypes.byref(a)))
+    if aux and need > 0 and Plan.defer_reduces:
+        # a launch that leaves partial-sum slabs: its reduction is deferred (Plan.flush_reduces), so the slabs need a
+        # region of their own until then -- HBM is 288 GB, a backward plan's ~20 regions of 19 MB are not
+        ws = torch.empty(need, dtype=torch.uint8, device=src.device)
+        a.workspace, a.workspace_bytes, a.defer_reduce = ws.data_ptr(), need, 1
     plan.hold(a, src, dy, dw, pro, ws)
     plan.add(what, lib.combat_conv_wgrad, ctypes.byref(a), aux=aux)
     plan.wgrads.append((len(plan.calls) - 1, a))
+    if a.defer_reduce:
+        plan.pending_reduces.append((what + ".reduce", a, len(plan.calls) - 1))
 
 
 def balance_wgrads(plan: Plan, device) -> None:
@@ -486,6 +532,8 @@ def _pow2_part(pq: int, cap: int = 32) -> int:
 
 class NetEngine:
     """Shared machinery: parameters, packed operands, scratch, slots."""
+
+    flush_at_marks = False   # set (before any backward plan is built) by a data-parallel step: see Plan.flush_at_marks
 
     def __init__(self, module: torch.nn.Module):
         self.module = module
@@ -868,6 +916,7 @@ class PreActEngine(NetEngine):
         if key in slot.plans:
             return slot.plans[key]
         P = Plan("preact." + key)
+        P.flush_at_marks = self.flush_at_marks
         fp, n = self.fp, slot.N
         h = self.head_bufs(slot)
         P.add("zero_grad", _zero_grad_call, fp)
@@ -1086,6 +1135,7 @@ class ResNetEngine(PreActEngine):
         if key in slot.plans:
             return slot.plans[key]
         P = Plan("resnet." + key)
+        P.flush_at_marks = self.flush_at_marks
         fp = self.fp
         G = lambda name, like: slot.buf("g." + name, like.shape)
         P.add("zero_grad", _zero_grad_call, fp)
@@ -1292,6 +1342,7 @@ class UnetEngine(NetEngine):
         if "bwd" in slot.plans:
             return slot.plans["bwd"]
         P = Plan("unet.bwd")
+        P.flush_at_marks = self.flush_at_marks
         fp, n, hw, nf = self.fp, slot.N, slot.hw, self.nf
         pc = self.pc
         t = lambda name: slot.bufs["t." + name]

@@ -163,6 +163,8 @@ class AlternatedStep:
         self.netC, self.netG, self.clean_model, self.netF = netC, netG, clean_model, netF
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        if self.world > 1 or (FORCE_ALLREDUCE and process_group is not None):
+            self.eC.flush_at_marks = self.eG.flush_at_marks = True    # gradients above an all-reduce mark must be final there
         self.hw = opt.input_height
         self.N = 0
         dev = self.dev
@@ -597,6 +599,8 @@ class ClassifierStep:
             raise ValueError("ClassifierStep: unsupported generator %r (UnetGenerator or GridGenerator expected)" % type(netG).__name__)
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        if self.world > 1 or (FORCE_ALLREDUCE and process_group is not None):
+            self.eC.flush_at_marks = True
         self.hw = opt.input_height
         self.P = trigger.lowpass_matrix(self.hw, opt.ratio).to(self.dev)
         self.k1 = torch.zeros(3, dtype=f32, device=self.dev)

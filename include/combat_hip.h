@@ -179,9 +179,17 @@ typedef struct combat_wgrad_args {
                                     sums are combined by plain stores + one reduction launch instead
                                     of fp32 atomics (the chip sustains ~1.3 TB/s of those) */
     int64_t workspace_bytes;
+    int32_t defer_reduce;        /* 1: a launch that leaves partial sums in `workspace` does NOT combine them; the caller
+                                    issues combat_conv_wgrad_reduce(a) later -- on any stream ordered after this launch,
+                                    with the workspace untouched in between -- so that a chain of weight gradients is not
+                                    a chain of (kernel, reduction) pairs.  Launches that need no reduction ignore it. */
+    int32_t reserved;
 } combat_wgrad_args;
 
 int combat_conv_wgrad(const combat_wgrad_args *a, void *stream);
+/* dw += the partial sums a combat_conv_wgrad(a) launch with defer_reduce = 1 left in a->workspace (a no-op returning
+ * COMBAT_OK where that launch needed no reduction).  `a` must be the same arguments. */
+int combat_conv_wgrad_reduce(const combat_wgrad_args *a, void *stream);
 /* scratch bytes the launch for these args can use (0: none) */
 int64_t combat_conv_wgrad_workspace_bytes(const combat_wgrad_args *a);
 
@@ -477,6 +485,9 @@ typedef struct combat_plan combat_plan;
 combat_plan *combat_plan_create(void);
 void combat_plan_destroy(combat_plan *plan);
 int combat_plan_record(combat_plan *plan, int32_t queue);
+/* the call recorded last additionally waits (on its own stream) for the completion of recorded call `call_index`
+ * (0-based, earlier, on any queue): a reduction on the plan's stream behind a weight gradient on an auxiliary one */
+int combat_plan_set_after(combat_plan *plan, int32_t call_index);
 int combat_plan_record_cancel(void);   /* disarm (the call made was not a capturable entry point); 1 if it was armed */
 int32_t combat_plan_size(const combat_plan *plan);
 int combat_plan_run(combat_plan *plan, int32_t begin, int32_t end, void *stream, void *const *aux_streams, int32_t n_aux);

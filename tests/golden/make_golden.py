@@ -798,11 +798,23 @@ def golden_end_metric(name="end_metric.npz", threads=8, cfg=None):
     save(name, out)
 
 
-def golden_end_metric_perturbed():
-    """The same pipeline with a different reduction order inside the CPU kernels (4 threads instead of 8): how far two
-    fp32 runs of the REFERENCE are apart in the end metrics -- the floor under any tolerance on them."""
-    golden_end_metric("end_metric_perturbed.npz", threads=4)
-
+def golden_end_metric_perturbed(threads=(4, 3, 5)):
+    """The same pipeline, same data, same recorded draws, run again with nothing changed but the reduction order inside
+    the CPU kernels (thread count 4, 3, 5 instead of 8): how far fp32 runs of the REFERENCE modules are apart from
+    each other in the end metrics -- the alternated training is chaotic at the reference's lr = 1e-2 (DESIGN.md
+    section 4), so its end metrics are a distribution, and this is the sample of it the GPU test compares with.
+    Keeps eval.py's numbers of every run (end_metric_perturbed.npz).  ~15 min per run on 8 cores."""
+    runs = {k: [] for k in ("clean", "bd_ba", "bd_asr", "bd_n")}
+    for th in threads:
+        golden_end_metric("_end_metric_tmp.npz", threads=th)
+        tmp = os.path.join(HERE, "_end_metric_tmp.npz")
+        a = dict(np.load(tmp))
+        os.remove(tmp)
+        for k in runs:
+            runs[k].append(int(a["D/" + k]))
+    out = {"runs/" + k: np.array(v) for k, v in runs.items()}
+    out["runs/threads"] = np.array(list(threads))
+    save("end_metric_perturbed.npz", out)
 
 
 def _wanet_warp(x, noise, rescale=0.15):
@@ -1046,4 +1058,5 @@ if __name__ == "__main__":
     golden_wanet_trajectory()
     golden_victim_wanet()
     golden_end_metric()
+    golden_end_metric_perturbed()
     golden_config()

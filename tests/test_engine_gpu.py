@@ -548,6 +548,51 @@ def test_backward_plans_do_not_share_weight_gradient_scratch(mods):
         engine.Plan.default_aux_queues = 1
 
 
+def test_deferred_weight_gradient_reductions(mods):
+    """combat_wgrad_args.defer_reduce + combat_conv_wgrad_reduce + combat_plan_set_after (opt-in: COMBAT_DEFER_REDUCE=1;
+    measured slower on the step, see engine.Plan.defer_reduces): a training backward plan whose slab reductions run
+    on the plan's own stream, each behind its weight-gradient launch on the auxiliary queue, gives the gradients of
+    the default plan (reduction right behind each kernel) -- in C replay, Python replay and in line."""
+    nets, ops, engine = mods["nets"], mods["ops"], mods["engine"]
+    from combat_amd._lib import lib
+    gen = torch.Generator().manual_seed(4)
+    x = torch.rand(128, 3, 32, 32, generator=gen) * 2 - 1
+    t = torch.randint(0, 10, (128,), generator=gen)
+    m = seeded(nets.PreActResNet18, 0).cuda()
+    eng = m._net_engine()
+    eng.refresh()
+    names = [k for k, _ in m.named_parameters()]
+
+    def build(tag, defer):
+        engine.Plan.defer_reduces = defer
+        try:
+            slot = eng.slot(tag, 128, 32)
+            ops.image_to_c8(x.cuda(), eng.input(slot))
+            eng.head_bufs(slot)["targets"].copy_(t.cuda())
+            eng.forward_plan(slot, True).run()
+            return eng.backward_train_plan(slot)
+        finally:
+            engine.Plan.defer_reduces = False
+
+    def grads(run):
+        run()
+        torch.cuda.synchronize()
+        return {k: eng.fp.logical(eng.fp.grad, k).detach().float().cpu().clone() for k in names}
+
+    ref_plan, plan = build("defer.ref", False), build("defer.on", True)
+    n_red = sum(1 for f, _, _ in plan.calls if f is lib.combat_conv_wgrad_reduce)
+    assert n_red >= 12 and len(plan.after) == n_red and not any(f is lib.combat_conv_wgrad_reduce for f, _, _ in ref_plan.calls)
+    ref = grads(ref_plan.run)
+    for mode in ("c", "py", "serial"):
+        engine.Plan.compiled, engine.Plan.serial = mode != "py", mode == "serial"
+        try:
+            got = grads(plan.run)
+        finally:
+            engine.Plan.compiled, engine.Plan.serial = True, False
+        for k in names:
+            assert rel_l2(got[k], ref[k]) < 1e-5, (mode, k, rel_l2(got[k], ref[k]))
+
+
 def test_plan_replay_in_c_equals_python_replay(mods):
     """combat_plan_run (csrc/plan.cpp: the launch list walked in C, hand-off events reused) against the Python replay
     of the same plans.  Deterministic plans (the eval-mode forward: no atomics anywhere) must give BIT-identical

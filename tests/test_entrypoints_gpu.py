@@ -115,7 +115,8 @@ def test_wanet_workflow_on_synthetic_data(tmp_path):
     assert os.path.isdir(imgs) and any(f.endswith(".ppm") for f in os.listdir(imgs)) or "tensorboard" in sys.modules
     # train_victim.py refuses the WaNet generator by name; eval.py accepts it
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_victim.py"), "--synthetic", "--synthetic_size", "256", "--bs", "64",
-                        "--checkpoints", os.path.join(cwd, "ckpt"), "--load_checkpoint", "train_generator_wanet_clean", "--n_iters", "1"],
+                        "--checkpoints", os.path.join(cwd, "ckpt"), "--saving_prefix", "train_victim_refused", "--load_checkpoint",
+                        "train_generator_wanet_clean", "--n_iters", "1"],
                        cwd=cwd, env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "train_victim_wanet.py" in (r.stdout + r.stderr)
     out = run("eval.py", "--saving_prefix", "train_generator_wanet", "--load_checkpoint_clean", "train_victim_wanet_clean",
