@@ -458,8 +458,21 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
-    log("timed region: %.3f s (%.3f ms/step; host enqueue %.3f ms/step)" % (elapsed, elapsed / args.steps * 1e3,
-                                                                              host_s / args.steps * 1e3))
+    log("timed region: %.3f s (%.3f ms/step; host thread inside run() %.3f ms/step -- it runs ahead of the device until the "
+        "hardware queues fill and then moves at the device's pace)" % (elapsed, elapsed / args.steps * 1e3, host_s / args.steps * 1e3))
+    # the host's own cost of enqueueing a step: the device is parked behind a spin kernel, so no call waits for queue space
+    # (three steps = ~2 100 queue packets fit); outside the timed region
+    host_ms = None
+    if world == 1:
+        torch.cuda._sleep(int(2.0e9 * 0.04))
+        h0 = time.perf_counter()
+        for i in range(3):
+            x, t = batches[i % len(batches)]
+            st.run(x, t)
+        host_ms = (time.perf_counter() - h0) / 3 * 1e3
+        torch.cuda.synchronize()
+        log("host enqueue %.3f ms/step (device parked: the cost of the %s replay + the step's own host work)" % (
+            host_ms, "C (combat_plan_run)" if os.environ.get("COMBAT_PLAN_PY", "0") != "1" else "Python"))
     metrics = st.read_metrics()
     finite = all(np.isfinite(v) for v in metrics.values())
 
@@ -495,7 +508,7 @@ def main():
                        "per_gpu_batch": opt.bs, "global_batch": opt.bs * world,
                        "parallelism": "dp%d (RCCL all-reduce of netC grads in Phase C, netG grads in Phase G)" % world,
                        "gflop_per_image_algorithmic": 11.67, "losses_finite": finite,
-                       "golden_gate": gate},
+                       "golden_gate": gate, "host_enqueue_ms_per_step": None if host_ms is None else round(host_ms, 3)},
             "roofline": roof,
         }
         if args.dataset != "cifar10":

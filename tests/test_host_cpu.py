@@ -433,3 +433,36 @@ def test_loader_batches_equal_totensor_normalize_bit_for_bit():
         ref = ((torch.from_numpy(x)[idx].float() / 255.0) - 0.5) / 0.5
         assert torch.equal(xb, ref) and torch.equal(yb, torch.from_numpy(y)[idx])
     assert got[0][2].data_ptr() != got[1][2].data_ptr()
+
+
+def test_make_grid_matches_torchvision_semantics(tmp_path):
+    """combat_amd.log.make_grid / image_grid / ScalarWriter.add_image: the reference's image logging
+    (train_generator.py:310-315: torch.cat([inputs, inputs_bd], dim=2) -> Denormalizer -> torchvision.utils.make_grid(
+    normalize=True) -> add_image).  torchvision is absent; the expectations below are make_grid's documented
+    behaviour: ONE min-max range over the whole batch, nrow = 8 images per row, 2 pixels of zero padding around and
+    between images, single-channel images repeated to three channels."""
+    from combat_amd import log
+    b = torch.arange(3 * 1 * 2 * 2, dtype=torch.float32).view(3, 1, 2, 2) - 4.0      # values -4 .. 7
+    g = log.make_grid(b, normalize=True)
+    assert tuple(g.shape) == (3, 2 + 2 * 2, 3 * (2 + 2) + 2)
+    assert float(g.min()) == 0.0 and abs(float(g.max()) - 1.0) < 1e-6
+    assert torch.equal(g[0], g[1]) and torch.equal(g[1], g[2])
+    want = (b[1, 0] + 4.0) / 11.0
+    assert torch.allclose(g[0, 2:4, 6:8], want, atol=1e-6)                           # second image at column 2 + (2 + 2)
+    assert float(g[:, :2].abs().sum()) == 0.0 and float(g[:, :, 4:6].abs().sum()) == 0.0   # padding stays zero
+    ten = log.make_grid(torch.rand(10, 3, 4, 4), normalize=True)
+    assert tuple(ten.shape) == (3, 2 * (4 + 2) + 2, 8 * (4 + 2) + 2)                 # 8 per row, 2 rows
+
+    class O:
+        dataset = "cifar10"
+
+    x, xb = torch.rand(4, 3, 8, 8) * 2 - 1, torch.rand(4, 3, 8, 8) * 2 - 1
+    grid = log.image_grid(x, xb, O())
+    assert tuple(grid.shape) == (3, 16 + 4, 4 * (8 + 2) + 2)                          # clean images on top of their copies
+    assert torch.allclose(log.denormalize(x, O()), x * 0.5 + 0.5)
+    w = log.ScalarWriter(str(tmp_path))
+    w.add_image("Images", grid, global_step=20)
+    if w.tb is None:
+        path = tmp_path / "images" / "Images_000020.ppm"
+        raw = path.read_bytes()
+        assert raw.startswith(b"P6\n42 20\n255\n") and len(raw) == len(b"P6\n42 20\n255\n") + 42 * 20 * 3
