@@ -463,7 +463,7 @@ def main():
     # the host's own cost of enqueueing a step: the device is parked behind a spin kernel, so no call waits for queue space
     # (three steps = ~2 100 queue packets fit); outside the timed region
     host_ms = None
-    if world == 1:
+    if world == 1 and not args.no_roofline:      # (not in profiling runs: the spin kernel would sit in their traces)
         torch.cuda._sleep(int(2.0e9 * 0.04))
         h0 = time.perf_counter()
         for i in range(3):

@@ -100,8 +100,31 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     // fragment read folds into its 16-bit immediate: four 16-KB x slots span exactly 64 KB -> ONE set of address registers.
     constexpr int XBYTES = HPW * 8192, DYBYTES = 64 * 128, DYBASE = NS * XBYTES;
     constexpr int NDMA = 1 + HPW;                           // DMA instructions per wave and stage
+    // The LDS-DMA is issued from inline asm (resource words in SGPRs, LDS address through M0).  With the builtin, the
+    // compiler guards the first transposing LDS read behind a DMA it knows of with `s_waitcnt vmcnt(0)`: every patch's
+    // MFMAs then waited for the patch issued just before them -- two patches ahead in the ring -- to LAND, i.e. the ring
+    // never overlapped anything (2 600 cycles per patch for 1 152 of MFMA).  Unknown to the compiler, the DMA is ordered
+    // by the counted waits below alone, as designed.  (COMBAT_WGRAD_BUILTIN_DMA: the old form, for A/B timing.)
+    auto rsrc_words = [&](const void *ptr, unsigned bytes) __attribute__((always_inline)) {
+        const unsigned long base = (unsigned long)ptr;
+        u32x4_t w;
+        w[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
+        w[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
+        w[2] = __builtin_amdgcn_readfirstlane(bytes);
+        w[3] = 0x00020000u;
+        return w;
+    };
+    const u32x4_t xrs = rsrc_words(a.src, p.x_bytes), dyrs = rsrc_words(a.dy, p.dy_bytes);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_t *)smem) + wid * 1024;
+#ifdef COMBAT_WGRAD_BUILTIN_DMA
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t dyrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.dy), 0, p.dy_bytes, 0x00020000);
+#define COMBAT_W3_DMA(rs_builtin, rs_words, lds_off, voff) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_builtin, (lds_void_t *)(smem + (lds_off) + wid * 1024), 16, voff, 0, 0, 0)
+#else
+#define COMBAT_W3_DMA(rs_builtin, rs_words, lds_off, voff) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds0_l + (unsigned)(lds_off)), "v"(voff), "s"(rs_words##_l) : "memory")
+#endif
 
     // ---- DMA bookkeeping that does not depend on the patch: this lane's row of every piece it issues
     // (decoded position for the border tests, byte offset relative to the patch origin with the channel
@@ -155,15 +178,19 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     auto issue_piece = [&](auto j_tag, auto slot_tag) __attribute__((always_inline)) {
         constexpr int j = decltype(j_tag)::value;
         constexpr int slot_i = decltype(slot_tag)::value;
+        // (named copies: an asm operand inside a generic lambda does not capture the enclosing function's variable)
+        const u32x4_t xrs_l = xrs, dyrs_l = dyrs;
+        const unsigned lds0_l = lds0;
+        (void)xrs_l; (void)dyrs_l; (void)lds0_l;
         if constexpr (j == 0) {
             const unsigned off = is_img0 + dti[0] < a.N ? (unsigned)(is_dorg + drel[0]) : kOob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dyrsrc, (lds_void_t *)(smem + DYBASE + slot_i * DYBYTES + wid * 1024), 16, off, 0, 0, 0);
+            COMBAT_W3_DMA(dyrsrc, dyrs, DYBASE + slot_i * DYBYTES, off);
         } else if constexpr (j <= HPW) {
             const int d = hdec[j - 1];
             const bool ok = d >= 0 && is_img0 + (d >> 16) < a.N && (unsigned)(is_oy0 + ((d >> 8) & 255) - 1) < (unsigned)H &&
                             (unsigned)(is_ox0 + (d & 255) - 1) < (unsigned)W;
             const unsigned off = ok ? (unsigned)(is_xorg + hrel[j - 1]) : kOob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void_t *)(smem + slot_i * XBYTES + (wid + 8 * (j - 1)) * 1024), 16, off, 0, 0, 0);
+            COMBAT_W3_DMA(xrsrc, xrs, slot_i * XBYTES + 8 * (j - 1) * 1024, off);
         }
     };
     auto issue = [&](auto slot_tag) __attribute__((always_inline)) {   // a whole patch at once (the first NS - 1)

@@ -466,3 +466,58 @@ def test_make_grid_matches_torchvision_semantics(tmp_path):
         path = tmp_path / "images" / "Images_000020.ppm"
         raw = path.read_bytes()
         assert raw.startswith(b"P6\n42 20\n255\n") and len(raw) == len(b"P6\n42 20\n255\n") + 42 * 20 * 3
+
+
+def test_conv_pair_rejects_what_the_single_call_rejects(L):
+    """combat_conv_gemm_pair promises the results of two combat_conv_gemm calls, so it must return EINVAL
+    -- before any kernel dereferences a shape -- wherever the single call does, for either of its two problems."""
+    def good():
+        a = L.ConvArgs()
+        a.src = a.wpack = a.dst = 4096
+        a.N, a.H, a.W, a.C, a.P, a.Q, a.K = 4, 16, 16, 64, 8, 8, 128
+        a.R = a.S = 3
+        a.stride, a.pad, a.kpad, a.rows_pad = 2, 1, 576, 128
+        return a
+
+    def breakers():
+        def f(a): a.act_dst = 4096                       # activated output without its tables
+        yield f
+        def f(a): a.pro_scale = 4096                     # prologue scale without shift
+        yield f
+        def f(a): a.mask_scale = 4096                    # mask scale without shift
+        yield f
+        def f(a): a.mask_mul_scale = 1                   # multiply by a scale that is not there
+        yield f
+        def f(a): a.stats_kind = 2; a.stats = 4096       # norm-backward statistics without mask / xhat tables
+        yield f
+        def f(a): a.stats_kind = 1                       # statistics without a buffer
+        yield f
+        def f(a): a.kpad = 100                           # kpad not a multiple of 64
+        yield f
+        def f(a): a.C = 48; a.kpad = 448                 # channel count not a power of two
+        yield f
+        def f(a): a.stride = 3
+        yield f
+        def f(a): a.R = 2; a.S = 2
+        yield f
+        def f(a): a.N = 1 << 30                          # M overflow
+        yield f
+        def f(a): a.src = None
+        yield f
+
+    for brk in breakers():
+        bad = good()
+        brk(bad)
+        assert L.lib.combat_conv_gemm(ctypes.byref(bad), None) == -1
+        assert L.lib.combat_conv_gemm_pair(ctypes.byref(bad), ctypes.byref(good()), None) == -1
+        assert L.lib.combat_conv_gemm_pair(ctypes.byref(good()), ctypes.byref(bad), None) == -1
+    # the plan API rejects nonsense without touching a device
+    assert L.lib.combat_plan_record(None, -1) == -1 and L.lib.combat_plan_size(None) == -1
+    cp = L.lib.combat_plan_create()
+    assert L.lib.combat_plan_set_after(cp, 0) == -1                         # nothing recorded yet
+    assert L.lib.combat_plan_record(cp, -1) == 0 and L.lib.combat_memset_zero(4096, 16, None) == 0
+    assert L.lib.combat_plan_record(cp, 0) == 0 and L.lib.combat_memset_zero(4096, 16, None) == 0
+    assert L.lib.combat_plan_size(cp) == 2 and L.lib.combat_plan_set_after(cp, 0) == 0 and L.lib.combat_plan_set_after(cp, 1) == -1
+    assert L.lib.combat_plan_run(cp, 0, 3, None, None, 0) == -1             # range beyond the plan
+    assert L.lib.combat_plan_record_cancel() == 0                           # (nothing left armed)
+    L.lib.combat_plan_destroy(cp)
