@@ -462,25 +462,45 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
 #endif
 }
 
-__device__ __forceinline__ const GatherParams &pick(const GatherParams &a, const GatherParams &b, int n0) {
-    return blockIdx.x >= (unsigned)n0 ? b : a;
-}
+// (the host pass cannot instantiate the FINISH = false body -- device-only builtins in its signature-dependent
+// lambdas -- so the kernels below call it in the device pass only; the host pass needs just their stubs)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define COMBAT_GATHER_BODY(BN, NS, P) conv_gather_dma_body<BN, false, NS>(P)
+#else
+#define COMBAT_GATHER_BODY(BN, NS, P) ((void)(P))
+#endif
 
 struct GatherPair {
     GatherParams p[2];
     int n0;
 };
 
-// Workgroups [0, n0) run problem 0, the rest problem 1 (n0 = the whole grid for an ordinary launch).  Two independent
+// ONE problem per launch: the parameter block's fields sit at fixed kernel-argument offsets, so the compiler keeps what
+// the main loop needs in scalar registers.  (Round 2 ran every launch through the pair kernel below, whose body took
+// `blockIdx.x >= n0 ? p[1] : p[0]` as a REFERENCE: a run-time pointer into the kernel-argument segment -- the compiler
+// then re-loaded fields from memory inside the loop, 8 dependent `s_load_dword` + `s_waitcnt lgkmcnt(0)` per
+// reduction step (271 scalar loads in the kernel against ~17 in its siblings), each of which also drains the wave's
+// LDS reads: most of the "450-600 cycles of DMA issue per step" of DESIGN.md section 3.)
+template <int BN, int NS>
+__global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_kernel(const GatherParams p) {
+    COMBAT_GATHER_BODY(BN, NS, p);
+}
+
+// Workgroups [0, n0) run problem 0, the rest problem 1.  Two independent
 // convolutions in ONE launch: a residual block's stride-2 first convolution and its 1x1 shortcut (preact_resnet.py:33-36,
 // resnet.py:24-31: both read the same activated tensor) -- the shortcut's 0.6 GFLOP ride along in slots the 3x3 launch
-// leaves idle instead of paying a dependent 12-17 us launch of their own.
+// leaves idle instead of paying a dependent 12-17 us launch of their own.  The body is instantiated once per problem
+// behind a uniform branch, so that each copy addresses its parameters statically (see above).
 template <int BN, int NS>
-__global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_kernel(const GatherPair pp) {
+__global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_pair_kernel(const GatherPair pp) {
     // (the second problem starts at a multiple of eight, so that its `index & 7` is again the blocks' XCD group: the
     // up-to-seven workgroups in between have nothing to do)
-    if (blockIdx.x >= (unsigned)pp.n0 && blockIdx.x < (unsigned)pp.p[1].block_base) return;
-    conv_gather_dma_body<BN, false, NS>(pick(pp.p[0], pp.p[1], pp.n0));
+    if (blockIdx.x >= (unsigned)pp.n0) {
+        if (blockIdx.x < (unsigned)pp.p[1].block_base) return;
+        COMBAT_GATHER_BODY(BN, NS, pp.p[1]);
+    } else {
+        COMBAT_GATHER_BODY(BN, NS, pp.p[0]);
+    }
 }
 template <int BN>
 __global__ __launch_bounds__(256, 2) void conv_gather_finish_kernel(const GatherParams p) { conv_gather_dma_body<BN, true, 3>(p); }
@@ -574,7 +594,10 @@ __device__ __forceinline__ void conv_c8_body(const GatherParams &p) {
                   m0 + BM > p.M, p.PQ, p.flavour);
 }
 
-__global__ __launch_bounds__(256, 3) void conv_c8_kernel(const GatherParams p) { conv_c8_body<64>(p); }
+#ifndef COMBAT_C8_WAVES
+#define COMBAT_C8_WAVES 3
+#endif
+__global__ __launch_bounds__(256, COMBAT_C8_WAVES) void conv_c8_kernel(const GatherParams p) { conv_c8_body<64>(p); }
 
 // Workgroups per tile for a launch with `tiles` tiles and `nsteps` reduction steps: split the reduction
 // only when the tiles alone leave most of the chip idle (skinny layers: 2x2 / 4x4 feature maps).
@@ -629,10 +652,8 @@ void fill(const combat_conv_args *a, GatherParams &p) {
 
 template <int BN>
 int launch(const combat_conv_args *a, hipStream_t st) {
-    GatherPair pp;           // (filled per call, passed by value: no host state shared between callers)
-    GatherParams &p = pp.p[0];
+    GatherParams p;          // (filled per call, passed by value: no host state shared between callers)
     fill<BN>(a, p);
-    pp.p[1].block_base = 0;
     constexpr int stage = 128 * 128 + BN * 128;
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
     constexpr int smem = (3 * stage > ep ? 3 * stage : ep) + 1024;   // (+ the weight prefetch's scratch KB)
@@ -649,8 +670,7 @@ int launch(const combat_conv_args *a, hipStream_t st) {
         attr_set = true;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    pp.n0 = tiles * (p.splits > 1 ? p.splits : 1);
-    hipLaunchKernelGGL(kern, dim3(pp.n0), dim3(256), smem, st, pp);
+    hipLaunchKernelGGL(kern, dim3(tiles * (p.splits > 1 ? p.splits : 1)), dim3(256), smem, st, p);
     CB_LAUNCH_CHECK();
     if (p.splits > 1) {
         hipLaunchKernelGGL(fin, dim3(tiles), dim3(256), ep, st, p);
@@ -750,7 +770,7 @@ int launch_pair(const combat_conv_args *a, const combat_conv_args *b, hipStream_
     constexpr int stage = 128 * 128 + BN * 128;
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
     constexpr int smem = (3 * stage > ep ? 3 * stage : ep) + 1024;
-    auto kern = conv_gather_dma_kernel<BN, 3>;
+    auto kern = conv_gather_dma_pair_kernel<BN, 3>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
