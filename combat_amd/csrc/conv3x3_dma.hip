@@ -428,7 +428,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
             if (s == 12345.678f) reinterpret_cast<float *>(const_cast<void *>(a.dst))[lane] = s;
         }
 #else
-        epi_finish<TE>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged, p.PQ, p.flavour);
+        epi_finish<TE>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged, p.PQ, p.flavour, NW);
 #endif
     } else {
         // two 32-pixel halves, one after the other (both halves' operand sets at once would be 136 registers on
@@ -513,6 +513,10 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
     const int first = blockIdx.x * p.per, left = p.tiles_m - first;
     const int cnt = left < p.per ? left : p.per;            // tiles of this workgroup (>= 1)
     const int ng = (cnt - grp + 1) >> 1;                      // ... of this group: first + grp, first + grp + 2, ...
+    constexpr int SVPL = EC::NC * 16 / 64;                  // statistics values per lane (epi_finish_fl)
+    float stat_run[SVPL];                                     // this wave's sums over all its tiles (per-workgroup rows)
+#pragma unroll
+    for (int u = 0; u < SVPL; ++u) stat_run[u] = 0.f;
 
     // Every LDS-DMA of this kernel is issued from inline asm (see the halo patch below for why): resources as four
     // scalar words, the LDS address through M0.
@@ -770,12 +774,35 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
                                  wait_vm_lgkm0<0>();
                                  WS_STAMP(8 + 6 * k);
                                  __builtin_amdgcn_sched_barrier(0);
+                             }, 0, [&](const float (&tot)[SVPL]) __attribute__((always_inline)) {
+#pragma unroll
+                                 for (int u = 0; u < SVPL; ++u) stat_run[u] += tot[u];
                              });
         WS_STAMP(9 + 6 * k);
         block_barrier();
     }
     // every wave executes the same number of barriers: A ran 1 + 2 ceil(cnt / 2), B 2 + 2 floor(cnt / 2)
     if ((cnt & 1) == grp) block_barrier();
+    // ---- one statistics row per workgroup (COMBAT_STATS_PER_WORKGROUP): the eight waves' running sums, added in wave order
+    if ((FL < 0 ? (a.stats_kind & 3) != 0 : (FL & (EF_STATS1 | EF_STATS2)) != 0) && (a.stats_kind & COMBAT_STATS_PER_WORKGROUP)) {
+        float *slots = reinterpret_cast<float *>(smem + EPI_OFF);     // (every epilogue is behind the barriers above)
+#pragma unroll
+        for (int u = 0; u < SVPL; ++u) slots[wid * (64 * SVPL) + lane * SVPL + u] = stat_run[u];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        block_barrier();
+        if (wid == 0) {
+            float sum[SVPL];
+#pragma unroll
+            for (int u = 0; u < SVPL; ++u) sum[u] = 0.f;
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int u = 0; u < SVPL; ++u) sum[u] += slots[w * (64 * SVPL) + lane * SVPL + u];
+            const int vg = (lane / EC::NC) * SVPL, n = (lane % EC::NC) * 8;
+            float *orow = a.stats + ((size_t)blockIdx.x * 2 + (vg >> 3)) * a.K + n + (vg & 7);
+#pragma unroll
+            for (int u = 0; u < SVPL; ++u) orow[u] = sum[u];
+        }
+    }
 #undef WS_STAMP
 }
 
@@ -895,13 +922,19 @@ int launch_ws_fl(const DmaParams &p, int blocks, hipStream_t st) {
     return COMBAT_OK;
 }
 
+// tiles per persistent workgroup / workgroups of the weight-stationary launch
+void ws_grid(int tiles_m, int &per, int &blocks) {
+    const int cus = 256;
+    per = (tiles_m + cus - 1) / cus;
+    if (per < 1) per = 1;
+    blocks = (tiles_m + per - 1) / per;
+}
+
 int launch_ws(const combat_conv_args *a, hipStream_t st) {
     DmaParams p;
     fill<16, 4, 32>(a, 64, p);
-    const int cus = 256;
-    p.per = (p.tiles_m + cus - 1) / cus;
-    if (p.per < 1) p.per = 1;
-    const int blocks = (p.tiles_m + p.per - 1) / p.per;
+    int blocks;
+    ws_grid(p.tiles_m, p.per, blocks);
     switch (p.flavour) {
         case 0: return launch_ws_fl<0>(p, blocks, st);
         case 1: return launch_ws_fl<1>(p, blocks, st);
@@ -938,12 +971,27 @@ int conv3x3d_pick(const combat_conv_args *a) {
 }
 
 int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {
-    if (tile == COMBAT_TILE_S128x64) tile = COMBAT_TILE_D128x64;     // same tiles, same rows
+    const bool per_wg = a->stats_kind & COMBAT_STATS_PER_WORKGROUP;
+    if (tile == COMBAT_TILE_S128x64) {
+        if (per_wg) {   // one row per persistent workgroup: whatever tiles it was dealt
+            if (!ws_applicable(a)) return COMBAT_EINVAL;
+            int per;
+            ws_grid(tiles_m_of(a), per, *rows);
+            *rows_per_image = 0;
+            return COMBAT_OK;
+        }
+        tile = COMBAT_TILE_D128x64;     // same tiles, same rows
+    }
     const int bn = tile_bn(tile);
     if (!bn || !applicable(a, bn)) return COMBAT_EINVAL;
     const int tw = geo_tw(a), bm = tile_bm(tile);
     const int th = geo_th(a, bm);
     if (!th) return COMBAT_EINVAL;
+    if (per_wg && tile != COMBAT_TILE_D256W64) {   // one row per tile (the wide-wave tile keeps its per-wave rows)
+        *rows = tiles_m_of(a, bm);
+        *rows_per_image = tw * th == bm ? (a->H * a->W) / bm : 0;
+        return COMBAT_OK;
+    }
     *rows = tiles_m_of(a, bm) * (bm / 32);   // one row per wave = 32 pixels
     *rows_per_image = ((tw * th) % 32 == 0) ? (a->H * a->W) / 32 : 0;
     return COMBAT_OK;

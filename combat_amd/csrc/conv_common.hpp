@@ -95,7 +95,7 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const f32x4_t
             load8f(a.mask_scale + n, msc);
             load8f(a.mask_shift + n, msh);
         }
-        if (a.stats_kind == 2) {
+        if ((a.stats_kind & 3) == 2) {
             load8f(a.xh_rstd + n, hrs);
             load8f(a.xh_mean + n, hmn);
         }
@@ -145,7 +145,7 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const f32x4_t
                         load8f(a.mask_scale + g + n, msc);
                         load8f(a.mask_shift + g + n, msh);
                     }
-                    if (a.stats_kind == 2) {
+                    if ((a.stats_kind & 3) == 2) {
                         load8f(a.xh_rstd + g + n, hrs);
                         load8f(a.xh_mean + g + n, hmn);
                     }
@@ -188,7 +188,7 @@ __device__ __forceinline__ void conv_epilogue(unsigned char *smem, const f32x4_t
             if (a.stats_kind) {
                 float vr[8];
                 unpack8(packed, vr);
-                if (a.stats_kind == 1) {
+                if ((a.stats_kind & 3) == 1) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         s1[e] += vr[e];

@@ -122,8 +122,8 @@ __host__ __device__ inline int epi_flags_of(const combat_conv_args &a) {
         if (a.mask_group_stride) f |= EF_PER_IMAGE;
     }
     if (a.act_dst) f |= EF_ACT;
-    if (a.stats_kind == 1) f |= EF_STATS1;
-    if (a.stats_kind == 2) f |= EF_STATS2;
+    if ((a.stats_kind & 3) == 1) f |= EF_STATS1;   // (bit 2 of stats_kind = one row per workgroup: a run-time matter)
+    if ((a.stats_kind & 3) == 2) f |= EF_STATS2;
     if (a.bias) f |= EF_BIAS;
     if (!a.dst) f |= EF_NODST;
     return f;
@@ -163,11 +163,20 @@ struct EpiNoHook {
 // pre_store(): called once, after the last use of the fetched operands and before the first global store (a
 // persistent caller waits for its in-flight LDS-DMA there: behind the stores, the in-order counter could only be
 // waited down together with them)
-template <typename T, int FL, typename PreStore = EpiNoHook>
+//
+// Statistics rows.  stats_kind 1 / 2: one row per wave (stats_row).  With COMBAT_STATS_PER_WORKGROUP set and
+// wg_waves > 0 (the caller's promise that all wg_waves waves of the workgroup make this call, with
+// stats_row = first row of the workgroup + wid): the waves' sums meet in LDS behind one workgroup barrier and wave 0
+// writes row stats_row / wg_waves, the waves added in index order -- a quarter of the rows for the consumer to reduce
+// (what decides whether a 32 x 32 or 16 x 16 layer's BatchNorm needs a norm_stage1 launch first).  stat_sink (a
+// persistent caller that owns no barrier here): receives this call's sums instead, `tot[v]` = sum of value
+// (lane / NC) * VPL + v of channel chunk lane % NC, and writes its one row itself.
+template <typename T, int FL, typename PreStore = EpiNoHook, typename StatSink = EpiNoHook>
 __device__ __forceinline__ void epi_finish_fl(EpiRegs<T> &er, unsigned char *smem, const f32x4_t (&acc)[T::FN][T::FM],
                                               const combat_conv_args &a, unsigned dst_bytes, int lane, int wid, int n0,
                                               long stats_row, bool ragged, int PQ, const lds_f32_t *lds_tabs = nullptr,
-                                              PreStore pre_store = PreStore()) {
+                                              PreStore pre_store = PreStore(), int wg_waves = 0,
+                                              StatSink stat_sink = StatSink()) {
     // lds_tabs: the per-channel tables this body would fetch from global memory (bias, xh_rstd, xh_mean: K floats
     // each, in that order; absent ones as zeros), staged in LDS by a persistent caller -- a global load issued here,
     // behind that caller's in-flight LDS-DMA, could only be waited for together with the DMA (in-order vmcnt)
@@ -300,32 +309,58 @@ __device__ __forceinline__ void epi_finish_fl(EpiRegs<T> &er, unsigned char *sme
 #pragma unroll
         for (int q = 0; q < EQ; ++q) __builtin_amdgcn_raw_buffer_store_b128(packed_act[q], r_act, er.evoff[q], 0, 0);
     }
-    if ((kind1 || kind2) && stats_row >= 0) {
-        // one statistics row per wave (32 pixels).  Lanes with equal chunk differ by multiples of NC:
-        // one pass through the wave's LDS image ([lane][16] partial sums; lane -> (chunk, value pair))
-        // instead of log2(64 / NC) dependent cross-lane shuffles of 16 values each.
-        float *sp = ep + lane * 20;   // 16 values + pad: 80-byte pitch keeps the 16-byte stores conflict-free
-        *reinterpret_cast<f32x4_t *>(sp) = f32x4_t{s1[0], s1[1], s1[2], s1[3]};
-        *reinterpret_cast<f32x4_t *>(sp + 4) = f32x4_t{s1[4], s1[5], s1[6], s1[7]};
-        *reinterpret_cast<f32x4_t *>(sp + 8) = f32x4_t{s2[0], s2[1], s2[2], s2[3]};
-        *reinterpret_cast<f32x4_t *>(sp + 12) = f32x4_t{s2[4], s2[5], s2[6], s2[7]};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // NC chunks x 16 values = NC * 16 sums; lane handles chunk (lane % NC), values vg .. vg + VPL - 1
-        constexpr int VPL = NC * 16 / 64;            // values per lane (2 or 4)
+    if (kind1 || kind2) {
+        constexpr bool kSink = !__is_same(StatSink, EpiNoHook);
+        const bool per_wg = (kSink || wg_waves > 0) && (a.stats_kind & COMBAT_STATS_PER_WORKGROUP);
+        constexpr int VPL = NC * 16 / 64;            // values per lane (1, 2 or 4)
         const int vg = (lane / NC) * VPL;
         float tot[VPL];
 #pragma unroll
         for (int u = 0; u < VPL; ++u) tot[u] = 0.f;
+        if (stats_row >= 0) {
+            // the wave's 32 pixels.  Lanes with equal chunk differ by multiples of NC:
+            // one pass through the wave's LDS image ([lane][16] partial sums; lane -> (chunk, value pair))
+            // instead of log2(64 / NC) dependent cross-lane shuffles of 16 values each.
+            float *sp = ep + lane * 20;   // 16 values + pad: 80-byte pitch keeps the 16-byte stores conflict-free
+            *reinterpret_cast<f32x4_t *>(sp) = f32x4_t{s1[0], s1[1], s1[2], s1[3]};
+            *reinterpret_cast<f32x4_t *>(sp + 4) = f32x4_t{s1[4], s1[5], s1[6], s1[7]};
+            *reinterpret_cast<f32x4_t *>(sp + 8) = f32x4_t{s2[0], s2[1], s2[2], s2[3]};
+            *reinterpret_cast<f32x4_t *>(sp + 12) = f32x4_t{s2[4], s2[5], s2[6], s2[7]};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // NC chunks x 16 values = NC * 16 sums; lane handles chunk (lane % NC), values vg .. vg + VPL - 1
 #pragma unroll
-        for (int src = 0; src < 64 / NC; ++src) {
-            const float *rp = ep + (src * NC + ec) * 20 + vg;
+            for (int src = 0; src < 64 / NC; ++src) {
+                const float *rp = ep + (src * NC + ec) * 20 + vg;
 #pragma unroll
-            for (int u = 0; u < VPL; ++u) tot[u] += rp[u];
+                for (int u = 0; u < VPL; ++u) tot[u] += rp[u];
+            }
         }
         // value index v: 0..7 -> sum, 8..15 -> second moment, of channel n + (v & 7)
-        float *orow = a.stats + ((size_t)stats_row * 2 + (vg >> 3)) * K + n + (vg & 7);
+        if (!per_wg) {
+            if (stats_row >= 0) {
+                float *orow = a.stats + ((size_t)stats_row * 2 + (vg >> 3)) * K + n + (vg & 7);
 #pragma unroll
-        for (int u = 0; u < VPL; ++u) orow[u] = tot[u];
+                for (int u = 0; u < VPL; ++u) orow[u] = tot[u];
+            }
+        } else if constexpr (kSink) {
+            stat_sink(tot);
+        } else {
+            float *slot = ep + lane * VPL;   // (this wave's image again: its reads above are complete, LDS runs in order)
+#pragma unroll
+            for (int u = 0; u < VPL; ++u) slot[u] = tot[u];
+            __syncthreads();
+            if (wid == 0) {
+                float sum[VPL];
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) sum[u] = 0.f;
+                for (int w = 0; w < wg_waves; ++w)
+#pragma unroll
+                    for (int u = 0; u < VPL; ++u) sum[u] += slot[w * EPW + u];
+                float *orow = a.stats + ((size_t)(stats_row / wg_waves) * 2 + (vg >> 3)) * K + n + (vg & 7);
+#pragma unroll
+                for (int u = 0; u < VPL; ++u) orow[u] = sum[u];
+            }
+        }
     }
 }
 
@@ -333,15 +368,16 @@ __device__ __forceinline__ void epi_finish_fl(EpiRegs<T> &er, unsigned char *sme
 template <typename T>
 __device__ __forceinline__ void epi_finish(EpiRegs<T> &er, unsigned char *smem, const f32x4_t (&acc)[T::FN][T::FM],
                                            const combat_conv_args &a, unsigned dst_bytes, int lane, int wid, int n0,
-                                           long stats_row, bool ragged, int PQ, int flavour) {
+                                           long stats_row, bool ragged, int PQ, int flavour, int wg_waves = 0) {
 #define COMBAT_EPI_CASE(i)                                                                                      \
     case i:                                                                                                     \
-        epi_finish_fl<T, kEpiFlavours[i]>(er, smem, acc, a, dst_bytes, lane, wid, n0, stats_row, ragged, PQ);   \
+        epi_finish_fl<T, kEpiFlavours[i]>(er, smem, acc, a, dst_bytes, lane, wid, n0, stats_row, ragged, PQ,   \
+                                          nullptr, EpiNoHook(), wg_waves);                                      \
         break;
     switch (flavour) {
         COMBAT_EPI_CASE(0) COMBAT_EPI_CASE(1) COMBAT_EPI_CASE(2) COMBAT_EPI_CASE(3) COMBAT_EPI_CASE(4)
     default:
-        epi_finish_fl<T, -1>(er, smem, acc, a, dst_bytes, lane, wid, n0, stats_row, ragged, PQ);
+        epi_finish_fl<T, -1>(er, smem, acc, a, dst_bytes, lane, wid, n0, stats_row, ragged, PQ, nullptr, EpiNoHook(), wg_waves);
     }
 #undef COMBAT_EPI_CASE
     static_assert(kNumEpiFlavours == 5, "one case per flavour");

@@ -369,7 +369,7 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
                 acc[i][j] = v;
             }
         epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
-                      m0 + BM > p.M, p.PQ, p.flavour);
+                      m0 + BM > p.M, p.PQ, p.flavour, 4);
         return;
     }
     // wait until step `g + 1` has landed while the `k` younger steps issued after it stay in flight
@@ -453,7 +453,7 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         return;
     }
     epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
-                  m0 + BM > p.M, p.PQ, p.flavour);
+                  m0 + BM > p.M, p.PQ, p.flavour, 4);
 #ifdef COMBAT_STAMPS
     if (threadIdx.x == 0 && p.stamps) {
         p.stamps[blockIdx.x * 16 + 9] = GCLK() - c_loop_end;
@@ -591,7 +591,7 @@ __device__ __forceinline__ void conv_c8_body(const GatherParams &p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, fw[ks][i]),
                                                                     __builtin_bit_cast(bf16x8_t, fp[ks][j]), acc[i][j], 0, 0, 0);
     epi_finish<T>(epi, smem, acc, a, p.dst_bytes, lane, wid, n0, m0 + wid * 32 < p.M ? (long)(m0 / 32) + wid : -1L,
-                  m0 + BM > p.M, p.PQ, p.flavour);
+                  m0 + BM > p.M, p.PQ, p.flavour, 4);
 }
 
 #ifndef COMBAT_C8_WAVES

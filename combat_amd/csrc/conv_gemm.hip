@@ -370,8 +370,11 @@ extern "C" int combat_conv_stats_layout(const combat_conv_args *a, int32_t *rows
     if ((tile >= COMBAT_TILE_H256x64 && tile < COMBAT_TILE_G128x64) || tile == COMBAT_TILE_D256x64 || tile == COMBAT_TILE_D256W64 ||
         tile == COMBAT_TILE_S128x64)
         return conv3x3_stats_layout(a, tile, rows, rows_per_image);
-    const int gran = combat_conv_stats_granule(tile);
+    int gran = combat_conv_stats_granule(tile);
     if (gran <= 0) return COMBAT_EINVAL;
+    if ((a->stats_kind & COMBAT_STATS_PER_WORKGROUP) &&
+        (tile == COMBAT_TILE_G128x64 || tile == COMBAT_TILE_G128x32 || tile == COMBAT_TILE_C8))
+        gran = 128;   // the DMA kernels' workgroup tile
     const long M = (long)a->N * a->P * a->Q, PQ = (long)a->P * a->Q;
     *rows = (int)((M + gran - 1) / gran);
     *rows_per_image = (PQ % gran == 0) ? (int)(PQ / gran) : 0;
@@ -400,8 +403,11 @@ static int validate_conv_args(const combat_conv_args *a) {
     if ((a->pro_scale == nullptr) != (a->pro_shift == nullptr)) return COMBAT_EINVAL;
     if (a->mask_scale && !a->mask_shift) return COMBAT_EINVAL;
     if (a->mask_mul_scale && !a->mask_scale) return COMBAT_EINVAL;
-    if (a->stats_kind < 0 || a->stats_kind > 2 || (a->stats_kind && !a->stats)) return COMBAT_EINVAL;
-    if (a->stats_kind == 2 && (!a->mask_x || !a->xh_mean || !a->xh_rstd)) return COMBAT_EINVAL;
+    const int skind = a->stats_kind & 3;
+    if (a->stats_kind < 0 || (a->stats_kind & ~(3 | COMBAT_STATS_PER_WORKGROUP)) || skind == 3 || (!skind && a->stats_kind) ||
+        (skind && !a->stats))
+        return COMBAT_EINVAL;
+    if (skind == 2 && (!a->mask_x || !a->xh_mean || !a->xh_rstd)) return COMBAT_EINVAL;
     if (ilog2_exact(a->C) < 0) return COMBAT_EINVAL;   // channel counts on this path are powers of two
     if ((long)a->N * a->P * a->Q > 0x7fffffffL / 8) return COMBAT_EINVAL;
     return COMBAT_OK;

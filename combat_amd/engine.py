@@ -19,9 +19,15 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import CombatHipError, lib
+from ._lib import STATS_PER_WORKGROUP, CombatHipError, lib
 from .nets import UNET_LAYERS
 from .ops import Affine, PackedConv, bf16
+
+# Statistics over the whole batch (BatchNorm) ask the convolution for one partial row per workgroup instead of one per
+# wave: 256 rows instead of 1024-4096 on the 32 x 32 and 16 x 16 layers, so the fused normalisation launches reduce them
+# themselves and no norm_stage1 launch stands between a convolution and its normalisation (18 launches per alternated
+# step).  COMBAT_STATS_PER_WAVE=1 restores the per-wave rows (A/B measurements).
+BATCH_STATS_ROWS = 0 if os.environ.get("COMBAT_STATS_PER_WAVE") == "1" else STATS_PER_WORKGROUP
 
 f32 = torch.float32
 
@@ -607,6 +613,7 @@ class NetEngine:
         n, p, q, c = dst.shape
         pq, m = p * q, n * p * q
         a = ops.conv_args(src, dst, pc, 0, workspace=plan.workspace(src.device), **conv_kw)
+        a.stats_kind = 1 | (BATCH_STATS_ROWS if groups == 1 else 0)    # (the row layout depends on it)
         rows, rpi = ops.conv_stats_layout(a)
         fused = (groups == 1) or (rpi > 0)
         st = slot.norm.get(key)
@@ -616,8 +623,10 @@ class NetEngine:
         part = None
         if fused:
             part = slot.buf(key + ".part", (rows, 2, c), f32)
-            a.stats_kind, a.stats = 1, part.data_ptr()
+            a.stats = part.data_ptr()
             rpg = rows if groups == 1 else rpi
+        else:
+            a.stats_kind = 0
         plan.hold(a, part)
         plan.add(key + ".conv", lib.combat_conv_gemm, ctypes.byref(a))
         one_launch = act_dst is not None or defer
@@ -664,14 +673,17 @@ class NetEngine:
         groups = st.groups
         mask = Affine(st.scale, st.shift, group_stride, True, slope)
         a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask, workspace=plan.workspace(dy.device))
+        a.stats_kind = 2 | (BATCH_STATS_ROWS if groups == 1 else 0)
+        a.xh_mean, a.xh_rstd = st.mean.data_ptr(), st.rstd.data_ptr()
         rows, rpi = ops.conv_stats_layout(a)
         fused = (groups == 1) or (rpi > 0)
         part, rpg = None, 0
         if fused:
             part = slot.buf(key + ".bpart", (rows, 2, c), f32)
-            a.stats_kind, a.stats = 2, part.data_ptr()
-            a.xh_mean, a.xh_rstd = st.mean.data_ptr(), st.rstd.data_ptr()
+            a.stats = part.data_ptr()
             rpg = rows if groups == 1 else rpi
+        else:
+            a.stats_kind, a.xh_mean, a.xh_rstd = 0, None, None
         plan.hold(a, part)
         plan.add(key + ".dgrad", lib.combat_conv_gemm, ctypes.byref(a))
         if not fused and pq > self.FUSED_DIRECT_PX:

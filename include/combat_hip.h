@@ -92,7 +92,12 @@ typedef struct combat_conv_args {
     int32_t tanh_out;            /* v = tanh(v) */
     /* statistics of the stored (bf16-rounded) values, per granule of `stats_granule` rows:
        stats_kind 1: (sum v, sum v*v);  2: (sum v, sum v*xh) with xh = (mask_x - xh_mean)*xh_rstd.
-       layout fp32 [rows][2][K]; one row per wave of a tile (combat_conv_stats_layout). */
+       layout fp32 [rows][2][K]; one row per wave of a tile (combat_conv_stats_layout).
+       | COMBAT_STATS_PER_WORKGROUP: the DMA kernels write one row per workgroup instead (the waves' sums added
+       in wave order; the weight-stationary kernel: one row per persistent workgroup) -- for statistics over the
+       whole batch, whose consumer then has a quarter (or less) of the rows to reduce; rows no longer align with
+       images unless combat_conv_stats_layout says so.  Kernels without that form ignore the bit; the layout
+       call reports what the launch will write. */
     int32_t stats_kind;
     float *stats;
     const float *xh_mean, *xh_rstd;         /* group stride = mask_group_stride */
@@ -111,6 +116,7 @@ typedef struct combat_conv_args {
     int32_t tile;                /* 0 = auto; else a COMBAT_TILE_* value */
 } combat_conv_args;
 
+#define COMBAT_STATS_PER_WORKGROUP 4
 #define COMBAT_TILE_128x128 1
 #define COMBAT_TILE_128x64 2
 #define COMBAT_TILE_64x64 3

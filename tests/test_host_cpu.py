@@ -90,14 +90,31 @@ def test_tile_choice_and_stats_layout_are_host_queries(L):
     a.stride, a.pad, a.kpad, a.rows_pad = 1, 1, 576, 128
     assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_S128x64      # no prologue, C = K = 64, >= 2 tiles per CU:
     #                                                                             weight-stationary persistent kernel
+    rows, rpi = ctypes.c_int32(), ctypes.c_int32()
+    def layout(kind):
+        a.stats_kind = kind
+        assert L.lib.combat_conv_stats_layout(ctypes.byref(a), ctypes.byref(rows), ctypes.byref(rpi)) == 0
+        a.stats_kind = 0
+        return rows.value, rpi.value
+    assert layout(1) == (4096, 32)                                              # one row per wave: 32 per image
+    assert layout(1 | L.STATS_PER_WORKGROUP) == (256, 0)                        # one per persistent workgroup (4 tiles each)
     a.N = 48                                                                    # 384 tiles: the ring kernel
     assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_D128x64
+    assert layout(1) == (1536, 32) and layout(2 | L.STATS_PER_WORKGROUP) == (384, 8)   # ... one per 128-pixel tile
     a.N = 128
+    a.stats_kind = 8                                                            # unknown statistics bits
+    assert L.lib.combat_conv_gemm(ctypes.byref(a), None) == -1
+    a.stats_kind = L.STATS_PER_WORKGROUP                                        # the row-form bit without a kind
+    assert L.lib.combat_conv_gemm(ctypes.byref(a), None) == -1
+    a.stats_kind = 0
     a.pro_act = 1
     assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_H128x64      # prologue, big layer: halo 128x64
-    rows, rpi = ctypes.c_int32(), ctypes.c_int32()
     assert L.lib.combat_conv_stats_layout(ctypes.byref(a), ctypes.byref(rows), ctypes.byref(rpi)) == 0
     assert rows.value == 128 * 1024 // 32 and rpi.value == 32
+    a.stats_kind = 1 | L.STATS_PER_WORKGROUP                                    # (the register-staged kernels ignore the bit)
+    assert L.lib.combat_conv_stats_layout(ctypes.byref(a), ctypes.byref(rows), ctypes.byref(rpi)) == 0
+    assert rows.value == 128 * 1024 // 32 and rpi.value == 32
+    a.stats_kind = 0
     a.H = a.W = a.P = a.Q = 4
     a.C = a.K = 512
     a.kpad, a.rows_pad = 4608, 512

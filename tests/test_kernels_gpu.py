@@ -252,6 +252,67 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(ops, n, hw):
     assert lib.combat_conv_pick_tile(ctypes.byref(a)) == (17 if tiles >= 512 else (11 if tiles <= 256 else 10))
 
 
+@pytest.mark.parametrize("n,hw,c,k,stride,tile,waves", [
+    (5, 32, 64, 64, 1, 10, 4), (3, 16, 128, 128, 1, 10, 4), (5, 8, 128, 64, 1, 10, 4), (9, 4, 256, 256, 1, 11, 4),   # ring kernel (ragged N on small maps)
+    (3, 32, 64, 64, 1, 14, 8), (7, 8, 128, 64, 1, 14, 8),                   # ... 256-pixel tiles, eight waves
+    (3, 32, 64, 64, 1, 17, 0), (40, 32, 64, 64, 1, 17, 0), (81, 32, 64, 64, 1, 17, 0), (128, 32, 64, 64, 1, 17, 0),   # weight-stationary: 1, 1-2, 3, 4 tiles per workgroup
+    (5, 32, 64, 128, 2, 12, 4), (3, 16, 128, 256, 2, 13, 4), (3, 10, 64, 64, 2, 12, 4),   # gather kernel (stride 2; 3 x 25 = 75 pixels: ragged last tile)
+    (5, 32, 8, 64, 1, 15, 4)])                                               # C = 8 kernel
+def test_conv_statistics_one_row_per_workgroup(ops, n, hw, c, k, stride, tile, waves):
+    """COMBAT_STATS_PER_WORKGROUP: the same launch with one statistics row per workgroup instead of one per wave --
+    outputs unchanged, the layout call reports the smaller row count, and (kernels that meet in LDS: waves > 0) every row
+    is the sum of its workgroup's wave rows added in wave order, BIT-exactly; the persistent kernel's rows (one per
+    workgroup, over all its tiles) must add up to the same totals.  Forward (sum, second moment) and, at stride 1,
+    the train-mode input gradient (sum dz, sum dz * xhat behind the mask)."""
+    from combat_amd._lib import lib, STATS_PER_WORKGROUP
+    import ctypes
+    x = nhwc(torch.randn(n, c, hw, hw, generator=g(301)))
+    w, pc = make_conv(ops, k, c, 3, stride, 1, 302)
+    p, q = pc.out_hw(hw, hw)
+    res = nhwc(torch.randn(n, k, p, q, generator=g(303)))
+    cases = [("forward", lambda o, kind: ops.conv_args(x, o, pc, 0, add_post=res, stats_kind=kind, tile=tile), (n, p, q, k))]
+    if stride == 1 and c >= 64:
+        dy = nhwc(torch.randn(n, k, hw, hw, generator=g(304)))
+        xpre = nhwc(torch.randn(n, c, hw, hw, generator=g(305)))
+        aff = ops.Affine(dev(torch.rand(c, generator=g(306)) + 0.5), dev(torch.randn(c, generator=g(307)) * 0.3), 0, True, 0.0)
+        mean, rstd = dev(torch.randn(c, generator=g(308)) * 0.1), dev(torch.rand(c, generator=g(309)) + 0.5)
+        cases.append(("train backward", lambda o, kind: ops.conv_args(dy, o, pc, 1, mask_x=xpre, mask=aff, stats_kind=kind,
+                                                                      xh_mean=mean, xh_rstd=rstd, tile=tile), (n, hw, hw, c)))
+    for name, make, oshape in cases:
+        outs = []
+        for extra in (0, STATS_PER_WORKGROUP):
+            o = torch.zeros(oshape, dtype=bf16, device="cuda")
+            a = make(o, (1 if name == "forward" else 2) | extra)
+            assert lib.combat_conv_pick_tile(ctypes.byref(a)) in ((12, 13) if tile in (12, 13) else (tile,)), name   # (the gather kernel sizes its channel tile itself)
+            rows, rpi = ops.conv_stats_layout(a)
+            stats = torch.full((rows + 1, 2, oshape[3]), 7.0, device="cuda")      # (+ a guard row)
+            a.stats = stats.data_ptr()
+            ops.conv_launch(a)
+            torch.cuda.synchronize()
+            assert torch.all(stats[rows] == 7.0), (name, "wrote beyond the reported rows")
+            outs.append((o, stats[:rows], rows, rpi))
+        (o_w, s_w, rows_w, _), (o_g, s_g, rows_g, rpi_g) = outs
+        assert torch.equal(o_w, o_g), name
+        assert rows_g < rows_w, (name, rows_g, rows_w)
+        if waves:
+            pad = rows_g * waves - rows_w             # (a ragged last tile has fewer waves inside the tensor)
+            assert 0 <= pad < waves, (name, rows_g, rows_w)
+            per = torch.cat([s_w, torch.zeros(pad, 2, s_w.shape[2], device="cuda")]).view(rows_g, waves, 2, -1)
+            acc = per[:, 0].clone()
+            for wv in range(1, waves):
+                acc += per[:, wv]
+            assert torch.equal(acc, s_g), name
+            if rpi_g:     # rows of one image are contiguous and complete
+                ref = (o_g.float().view(n, -1, oshape[3]).sum(1), s_g.view(n, rpi_g, 2, -1)[:, :, 0].sum(1))
+                if name == "forward":
+                    assert rel_l2(ref[1], ref[0]) < 1e-4
+        else:
+            tiles = rows_w // 4
+            per = -(-tiles // 256)                       # tiles per persistent workgroup
+            assert rows_g == -(-tiles // per), (rows_g, rows_w)
+            assert rel_l2(s_g.sum(0).double(), s_w.sum(0).double()) < 1e-6, name
+
+
 @pytest.mark.parametrize("n,hw,c,k,r,stride,tile,keep_raw", [
     (4, 16, 64, 64, 3, 1, 0, True), (4, 16, 64, 128, 3, 1, 0, False),     # DMA-staged kernel
     (4, 16, 64, 64, 3, 1, 17, True), (41, 32, 64, 64, 3, 1, 17, False),   # ... weight-stationary persistent form
