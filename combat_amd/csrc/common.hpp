@@ -1,6 +1,7 @@
 // Shared device helpers for the combat_hip kernels (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "combat_hip.h"
@@ -12,6 +13,26 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 // into a local array lowers to an address-space-crossing memcpy that SROA does not promote, which
 // leaves the array in scratch memory (and every prefetch waits for its own load)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// Every kernel launch of the library goes through COMBAT_LAUNCH.  Normally it is hipLaunchKernelGGL.  While the plan
+// replayer (plan.cpp) has set this thread's `t_stop`, the launch carries that event as its completion event
+// (hipExtLaunchKernelGGL's stopEvent): the kernel's own dispatch packet signals it.  That is how a result is handed to
+// the auxiliary queue: an hipEventRecord between two kernels is a packet of its own in the producing queue and holds
+// the NEXT kernel of that queue back by 3-5 us (tools/micro/handoff_bench.hip: 11.8 us per kernel plain, 17.0 with
+// record + wait, 12.4 with the event on the launch) -- ~34 hand-offs sit on the critical queue of an alternated step.
+namespace combat_launch {
+extern thread_local hipEvent_t t_stop;
+extern thread_local bool t_stop_used;
+}  // namespace combat_launch
+#define COMBAT_LAUNCH(kernel, grid, block, smem, stream, ...)                                             \
+    do {                                                                                                  \
+        if (hipEvent_t stop_ = combat_launch::t_stop) {                                                   \
+            hipExtLaunchKernelGGL(kernel, grid, block, smem, stream, nullptr, stop_, 0, __VA_ARGS__);     \
+            combat_launch::t_stop_used = true;                                                            \
+        } else {                                                                                          \
+            hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);                           \
+        }                                                                                                 \
+    } while (0)
 
 #define CB_LAUNCH_CHECK()                                  \
     do {                                                   \

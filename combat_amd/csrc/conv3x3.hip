@@ -564,7 +564,7 @@ int launch_halo1(const HaloParams &p, int smem, hipStream_t st) {
             return COMBAT_ELAUNCH;
         attr_bytes = 150 * 1024;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    COMBAT_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -579,7 +579,7 @@ int launch_halo(const HaloParams &p, int smem, hipStream_t st) {
             return COMBAT_ELAUNCH;
         attr_bytes = 150 * 1024;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    COMBAT_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -867,7 +867,7 @@ int launch_hb(const DmaParams &p, hipStream_t st) {
             return COMBAT_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * NW), smem, st, p);
+    COMBAT_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * NW), smem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -917,7 +917,7 @@ int launch_ws_fl(const DmaParams &p, int blocks, hipStream_t st) {
             return COMBAT_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), kWsSmem, st, p);
+    COMBAT_LAUNCH(kern, dim3(blocks), dim3(512), kWsSmem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -670,10 +670,10 @@ int launch(const combat_conv_args *a, hipStream_t st) {
         attr_set = true;
     }
     const int tiles = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kern, dim3(tiles * (p.splits > 1 ? p.splits : 1)), dim3(256), smem, st, p);
+    COMBAT_LAUNCH(kern, dim3(tiles * (p.splits > 1 ? p.splits : 1)), dim3(256), smem, st, p);
     CB_LAUNCH_CHECK();
     if (p.splits > 1) {
-        hipLaunchKernelGGL(fin, dim3(tiles), dim3(256), ep, st, p);
+        COMBAT_LAUNCH(fin, dim3(tiles), dim3(256), ep, st, p);
         CB_LAUNCH_CHECK();
     }
     return COMBAT_OK;
@@ -724,7 +724,7 @@ int conv_c8_launch(const combat_conv_args *a, hipStream_t st) {
             return COMBAT_ELAUNCH;
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv_c8_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    COMBAT_LAUNCH(conv_c8_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -783,7 +783,7 @@ int launch_pair(const combat_conv_args *a, const combat_conv_args *b, hipStream_
     const int base1 = (n0 + 7) & ~7;
     pp.n0 = n0;
     pp.p[1].block_base = base1;
-    hipLaunchKernelGGL(kern, dim3(base1 + n1), dim3(256), smem, st, pp);
+    COMBAT_LAUNCH(kern, dim3(base1 + n1), dim3(256), smem, st, pp);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -303,7 +303,7 @@ int launch(const ConvParams &p, hipStream_t st) {
     q.mq = p.M / 4;
     q.cpt = p.a.C / 64;
     if (q.tiles_n * BN > p.a.rows_pad) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(kern, dim3(q.tiles_m * q.tiles_n), dim3(256), T::SMEM, st, q);
+    COMBAT_LAUNCH(kern, dim3(q.tiles_m * q.tiles_n), dim3(256), T::SMEM, st, q);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

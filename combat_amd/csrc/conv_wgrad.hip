@@ -436,10 +436,10 @@ int launch_c8(WgradParams p, hipStream_t st) {
     const int per_tile = 64 * 9 * p.a.c_real;
     const long need = (long)p.tiles_k * p.split * per_tile * 4;
     p.ws = (p.split > 1 && p.a.workspace && p.a.workspace_bytes >= need) ? reinterpret_cast<float *>(p.a.workspace) : nullptr;
-    hipLaunchKernelGGL(conv_wgrad_c8_kernel, dim3((unsigned)(p.tiles_k * p.split)), dim3(256), SMEM, st, p);
+    COMBAT_LAUNCH(conv_wgrad_c8_kernel, dim3((unsigned)(p.tiles_k * p.split)), dim3(256), SMEM, st, p);
     CB_LAUNCH_CHECK();
     if (p.ws) {
-        hipLaunchKernelGGL(conv_wgrad_c8_reduce_kernel, dim3((per_tile + 255) / 256, p.tiles_k, p.split >= 32 ? 16 : 1), dim3(256), 0, st, p.ws,
+        COMBAT_LAUNCH(conv_wgrad_c8_reduce_kernel, dim3((per_tile + 255) / 256, p.tiles_k, p.split >= 32 ? 16 : 1), dim3(256), 0, st, p.ws,
                            p.a.dw, p.tiles_k, p.split, per_tile, p.a.k_real, 9 * p.a.c_real);
         CB_LAUNCH_CHECK();
     }
@@ -475,7 +475,7 @@ int launch(WgradParams p, hipStream_t st) {
     p.pix_per_split = ((ktiles + split - 1) / split) * 64;
     p.split = (p.M + p.pix_per_split - 1) / p.pix_per_split;
     const long blocks = (long)p.tiles_k * p.tiles_c * p.ntaps * p.split;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), T::SMEM, st, p);
+    COMBAT_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), T::SMEM, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -312,7 +312,7 @@ int conv_wgrad3x3_try(const combat_wgrad_args *a, hipStream_t st) {
             return COMBAT_ELAUNCH;
         attr = true;
     }
-    hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3(base * p.split), dim3(256), smem, st, p);
+    COMBAT_LAUNCH(conv_wgrad3x3_kernel, dim3(base * p.split), dim3(256), smem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -459,7 +459,7 @@ int launch_w3d(const W3dParams &p, int blocks, hipStream_t st) {
             return COMBAT_ELAUNCH;
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(512), smem, st, p);
+    COMBAT_LAUNCH(kern, dim3(blocks), dim3(512), smem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -545,7 +545,7 @@ int launch_reduce(const combat_wgrad_args *a, const W3dParams &p, hipStream_t st
     int groups = (int)(512 / ((e4 + 255) / 256));
     if (groups < 1) groups = 1;
     if (groups > p.split) groups = p.split;
-    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3((unsigned)((e4 + 255) / 256), groups), dim3(256), 0, st, p.ws, a->dw, base,
+    COMBAT_LAUNCH(wgrad3x3_reduce_kernel, dim3((unsigned)((e4 + 255) / 256), groups), dim3(256), 0, st, p.ws, a->dw, base,
                        p.tiles_c, p.split, a->k_real, a->c_real);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;

@@ -495,7 +495,7 @@ extern "C" int combat_pack_weights(const float *w, int32_t K, int32_t taps, int3
     const int Kc = (K + 7) & ~7;
     if (wd && (rows_pad_d < C || kpad_d < taps * Kc || (kpad_d & 63))) return COMBAT_EINVAL;
     const long total = (long)rows_pad_f * kpad_f + (wd ? (long)rows_pad_d * kpad_d : 0);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, K, taps, c_real,
+    COMBAT_LAUNCH(pack_weights_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w, K, taps, c_real,
                        C, dup_hilo, reinterpret_cast<__bf16 *>(wf), rows_pad_f, kpad_f, reinterpret_cast<__bf16 *>(wd),
                        rows_pad_d, kpad_d, Kc);
     CB_LAUNCH_CHECK();
@@ -506,7 +506,7 @@ extern "C" int combat_pack_weights_batch(const combat_pack_desc *descs, int32_t 
     COMBAT_PLAN_HOOK(combat_pack_weights_batch, descs, n);
     if (!descs || n < 0) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(512, (unsigned)n), dim3(256), 0, as_stream(stream), descs);
+    COMBAT_LAUNCH(pack_weights_batch_kernel, dim3(512, (unsigned)n), dim3(256), 0, as_stream(stream), descs);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -515,7 +515,7 @@ extern "C" int combat_image_to_c8(const float *x, int32_t n, int32_t hw, void *o
     COMBAT_PLAN_HOOK(combat_image_to_c8, x, n, hw, out_c8);
     if (!x || !out_c8 || n < 0 || hw <= 0) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    hipLaunchKernelGGL(image_to_c8_kernel, dim3(grid_for((long)n * hw * hw)), dim3(256), 0, as_stream(stream), x, n,
+    COMBAT_LAUNCH(image_to_c8_kernel, dim3(grid_for((long)n * hw * hw)), dim3(256), 0, as_stream(stream), x, n,
                        hw * hw, reinterpret_cast<uint4 *>(out_c8));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -526,7 +526,7 @@ extern "C" int combat_nhwc_to_nchw_f32(const void *x, int32_t n, int32_t h, int3
     COMBAT_PLAN_HOOK(combat_nhwc_to_nchw_f32, x, n, h, w, C, c, out);
     if (!x || !out || n < 0 || h <= 0 || w <= 0 || c <= 0 || c > C) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((long)n * c * h * w)), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(nhwc_to_nchw_kernel, dim3(grid_for((long)n * c * h * w)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), n, h * w, C, c, out);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -537,7 +537,7 @@ extern "C" int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, in
     COMBAT_PLAN_HOOK(combat_nchw_to_nhwc_bf16, x, n, c, h, w, C, out);
     if (!x || !out || n < 0 || h <= 0 || w <= 0 || c <= 0 || c > C || (C & 7)) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for((long)n * h * w * C)), dim3(256), 0, as_stream(stream), x, n,
+    COMBAT_LAUNCH(nchw_to_nhwc_kernel, dim3(grid_for((long)n * h * w * C)), dim3(256), 0, as_stream(stream), x, n,
                        c, h * w, C, reinterpret_cast<__bf16 *>(out));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -554,7 +554,7 @@ extern "C" int combat_log_terms(const float *x, const float *xb, const float *ms
                                 const float *detector_logits, double *acc2, double *hits, void *stream) {
     COMBAT_PLAN_HOOK(combat_log_terms, x, xb, mse_partial, n, hw, detector_logits, acc2, hits);
     if (!x || !xb || !acc2 || n <= 0 || hw < 2) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(log_terms_kernel, dim3(3 * n), dim3(256), 0, as_stream(stream), x, xb, mse_partial, 3 * n, n, hw,
+    COMBAT_LAUNCH(log_terms_kernel, dim3(3 * n), dim3(256), 0, as_stream(stream), x, xb, mse_partial, 3 * n, n, hw,
                        detector_logits, n, acc2, hits);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -567,7 +567,7 @@ extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_o
     if (hipMemsetAsync(out, 0, sizeof(float) * c_out, st) != hipSuccess) return COMBAT_ELAUNCH;
     long ysplit = (rows + 2047) / 2048;   // ~8 rows per thread
     if (ysplit > 512) ysplit = 512;
-    hipLaunchKernelGGL(colsum_kernel, dim3((c_out + 7) / 8, (unsigned)ysplit), dim3(256), 0, st,
+    COMBAT_LAUNCH(colsum_kernel, dim3((c_out + 7) / 8, (unsigned)ysplit), dim3(256), 0, st,
                        reinterpret_cast<const __bf16 *>(x), (long)rows, C, c_out, out);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -576,7 +576,7 @@ extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_o
 extern "C" int combat_maxpool2(const void *x, int32_t n, int32_t h, int32_t w, int32_t C, void *out, void *stream) {
     COMBAT_PLAN_HOOK(combat_maxpool2, x, n, h, w, C, out);
     if (!x || !out || n <= 0 || h <= 0 || w <= 0 || (h & 1) || (w & 1) || (C & 7)) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for((long)n * (h / 2) * (w / 2) * (C / 8))), dim3(256), 0,
+    COMBAT_LAUNCH(maxpool2_kernel, dim3(grid_for((long)n * (h / 2) * (w / 2) * (C / 8))), dim3(256), 0,
                        as_stream(stream), reinterpret_cast<const __bf16 *>(x), n, h, w, C,
                        reinterpret_cast<__bf16 *>(out));
     CB_LAUNCH_CHECK();
@@ -587,7 +587,7 @@ extern "C" int combat_elu_affine(const void *x, int64_t rows, int32_t C, const f
                                  void *out, void *stream) {
     COMBAT_PLAN_HOOK(combat_elu_affine, x, rows, C, scale, shift, out);
     if (!x || !out || !scale || !shift || rows <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(elu_affine_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(elu_affine_kernel, dim3(grid_for(rows * (C / 8))), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), (long)rows, C, scale, shift,
                        reinterpret_cast<__bf16 *>(out));
     CB_LAUNCH_CHECK();
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const uint4 *__restrict_
 extern "C" int combat_relu_mask(const void *g, const void *act, int64_t elements, void *out, void *stream) {
     COMBAT_PLAN_HOOK(combat_relu_mask, g, act, elements, out);
     if (!g || !act || !out || elements <= 0 || (elements & 7)) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(elements / 8, 8192)), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(relu_mask_kernel, dim3(grid_for(elements / 8, 8192)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const uint4 *>(g), reinterpret_cast<const uint4 *>(act), (long)(elements / 8),
                        reinterpret_cast<uint4 *>(out));
     CB_LAUNCH_CHECK();
@@ -624,7 +624,7 @@ extern "C" int combat_affine_act(const void *x, int64_t rows, int32_t C, const f
     COMBAT_PLAN_HOOK(combat_affine_act, x, rows, C, scale, shift, group_rows, slope, out);
     if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || group_rows < 0) return COMBAT_EINVAL;
     if ((scale == nullptr) != (shift == nullptr)) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(affine_act_kernel, dim3(grid_for(rows * (C / 8), 8192)), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(affine_act_kernel, dim3(grid_for(rows * (C / 8), 8192)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), (long)rows, C, scale, shift, (long)group_rows, slope,
                        reinterpret_cast<__bf16 *>(out));
     CB_LAUNCH_CHECK();
@@ -639,7 +639,7 @@ extern "C" int combat_unet_up_fwd(const void *y, const float *sy, const float *t
     if (s && (!ss || !ts)) return COMBAT_EINVAL;
     UpArgs a{reinterpret_cast<const __bf16 *>(y), reinterpret_cast<const __bf16 *>(s), sy, ty, ss, ts, N, H, W, C,
              reinterpret_cast<__bf16 *>(out)};
-    hipLaunchKernelGGL(unet_up_fwd_kernel, dim3(grid_for((long)N * 4 * H * W * (C / 8), 8192)), dim3(256), 0,
+    COMBAT_LAUNCH(unet_up_fwd_kernel, dim3(grid_for((long)N * 4 * H * W * (C / 8), 8192)), dim3(256), 0,
                        as_stream(stream), a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -649,7 +649,7 @@ extern "C" int combat_unet_up_bwd(const void *d_out, const void *out, int32_t N,
                                   void *du, void *stream) {
     COMBAT_PLAN_HOOK(combat_unet_up_bwd, d_out, out, N, H, W, C, du);
     if (!d_out || !out || !du || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(unet_up_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8), 8192)), dim3(256), 0,
+    COMBAT_LAUNCH(unet_up_bwd_kernel, dim3(grid_for((long)N * H * W * (C / 8), 8192)), dim3(256), 0,
                        as_stream(stream), reinterpret_cast<const __bf16 *>(d_out), reinterpret_cast<const __bf16 *>(out),
                        N, H, W, C, reinterpret_cast<__bf16 *>(du));
     CB_LAUNCH_CHECK();
@@ -663,7 +663,7 @@ extern "C" int combat_sgd_nesterov(const void *ptrs, const int64_t *sizes, int32
     if (!ptrs || !sizes || count <= 0 || max_size <= 0) return COMBAT_EINVAL;
     long bx = (max_size + 255) / 256;
     if (bx > 4096) bx = 4096;
-    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(sgd_kernel, dim3((unsigned)bx, (unsigned)count), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<void *const *>(ptrs), sizes, lr, momentum, weight_decay, grad_scale, first_step);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -673,7 +673,7 @@ extern "C" int combat_linear_nhwc(const void *x, int32_t n, int32_t h, int32_t w
                                   const float *b, int32_t classes, float *logits, void *stream) {
     COMBAT_PLAN_HOOK(combat_linear_nhwc, x, n, h, w, C, Wt, b, classes, logits);
     if (!x || !Wt || !b || !logits || n <= 0 || h <= 0 || w <= 0 || C <= 0 || classes <= 0) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(linear_nhwc_kernel, dim3(n), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(linear_nhwc_kernel, dim3(n), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), h, w, C, Wt, b, classes, logits);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;

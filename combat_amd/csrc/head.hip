@@ -161,7 +161,7 @@ extern "C" int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t 
             return COMBAT_ELAUNCH;
         attr = true;
     }
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), a);
+    COMBAT_LAUNCH(head_fwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -184,12 +184,12 @@ extern "C" int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32
             return COMBAT_ELAUNCH;
         attr = true;
     }
-    hipLaunchKernelGGL(head_bwd_feat_kernel, dim3(n), dim3(256), in_ * 4, st, logits, targets, loss_weight, n, hw, C,
+    COMBAT_LAUNCH(head_bwd_feat_kernel, dim3(n), dim3(256), in_ * 4, st, logits, targets, loss_weight, n, hw, C,
                        classes, W, dlogits, reinterpret_cast<__bf16 *>(d_feat));
     CB_LAUNCH_CHECK();
     if (dW) {
         const int in = C * (hw / 4) * (hw / 4);
-        hipLaunchKernelGGL(head_bwd_w_kernel, dim3((in + 255) / 256, classes, 8), dim3(256), 0, st, dlogits, pooled, n, in,
+        COMBAT_LAUNCH(head_bwd_w_kernel, dim3((in + 255) / 256, classes, 8), dim3(256), 0, st, dlogits, pooled, n, in,
                            classes, dW, db);
         CB_LAUNCH_CHECK();
     }

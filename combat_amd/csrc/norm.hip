@@ -803,7 +803,7 @@ const float *maybe_stage1(const float *partials, int groups, int &rows_per_group
         err = COMBAT_EINVAL;
         return nullptr;
     }
-    hipLaunchKernelGGL(norm_stage1_kernel, dim3((C + 63) / 64, groups, kStageRows), dim3(256), 0, st, partials,
+    COMBAT_LAUNCH(norm_stage1_kernel, dim3((C + 63) / 64, groups, kStageRows), dim3(256), 0, st, partials,
                        rows_per_group, C, scratch);
     if (hipGetLastError() != hipSuccess) {
         err = COMBAT_ELAUNCH;
@@ -835,7 +835,7 @@ extern "C" int combat_norm_finalize(const float *partials, int32_t groups, int32
     if (err) return err;
     FinalizeArgs a{src, rpg, C, count, eps, gamma, beta, mean, rstd, scale, shift, running_mean, running_var,
                    momentum, num_batches_tracked};
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, st, a);
+    COMBAT_LAUNCH(norm_finalize_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, st, a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -854,7 +854,7 @@ extern "C" int combat_norm_bwd_finalize(const float *partials, int32_t groups, i
     const float *src = maybe_stage1(partials, groups, rpg, C, scratch, scratch_bytes, st, err);
     if (err) return err;
     BwdFinalizeArgs a{src, rpg, C, count, gamma, mean, rstd, ca, cb, cc, dgamma, dbeta};
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, st, a);
+    COMBAT_LAUNCH(norm_bwd_finalize_kernel, dim3((C + 63) / 64, groups), dim3(256), 0, st, a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -883,7 +883,7 @@ static int norm_act_fused_launch(const void *x, const float *partials, int32_t g
                    (long)px_per_group, chunk, (float)px_per_group, eps, slope, gamma, beta, mean, rstd, scale, shift,
                    running_mean, running_var, momentum, num_batches_tracked, reinterpret_cast<const __bf16 *>(add),
                    add_scale, add_shift};
-    hipLaunchKernelGGL(norm_act_fused_kernel,
+    COMBAT_LAUNCH(norm_act_fused_kernel,
                        dim3((C + 63) / 64, (unsigned)((px_per_group + chunk - 1) / chunk), groups), dim3(256), 0, st, a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -930,7 +930,7 @@ extern "C" int combat_unet_up_fused(const void *y, const float *partials, int32_
     const int band = (Ho + bands - 1) / bands;
     UpFusedArgs a{reinterpret_cast<const __bf16 *>(y), reinterpret_cast<const __bf16 *>(s), reinterpret_cast<__bf16 *>(out),
                   partials, partials ? rows_per_group : 0, C, H, W, band, eps, ss, ts, mean, rstd, scale, shift};
-    hipLaunchKernelGGL(unet_up_fused_kernel, dim3(wg_c, (Ho + band - 1) / band, N), dim3(256), 0, as_stream(stream), a);
+    COMBAT_LAUNCH(unet_up_fused_kernel, dim3(wg_c, (Ho + band - 1) / band, N), dim3(256), 0, as_stream(stream), a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -945,7 +945,7 @@ extern "C" int combat_unet_up_bwd_fused(const void *d_out, const void *out, cons
     UpBwdFusedArgs a{reinterpret_cast<const __bf16 *>(d_out), reinterpret_cast<const __bf16 *>(out),
                      reinterpret_cast<const __bf16 *>(y), reinterpret_cast<__bf16 *>(du), reinterpret_cast<__bf16 *>(dx),
                      C, H, W, mean, rstd};
-    hipLaunchKernelGGL(unet_up_bwd_fused_kernel, dim3((C + 63) / 64, N), dim3(256), 0, as_stream(stream), a);
+    COMBAT_LAUNCH(unet_up_bwd_fused_kernel, dim3((C + 63) / 64, N), dim3(256), 0, as_stream(stream), a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -971,7 +971,7 @@ extern "C" int combat_norm_bwd_fused(const void *dz, const void *x, const void *
     FusedBwdArgs a{reinterpret_cast<const __bf16 *>(dz), reinterpret_cast<const __bf16 *>(x),
                    reinterpret_cast<const __bf16 *>(add), reinterpret_cast<__bf16 *>(dx), src, rpg, C,
                    (long)px_per_group, chunk, (float)px_per_group, gamma, mean, rstd, dgamma, dbeta};
-    hipLaunchKernelGGL(norm_bwd_fused_kernel,
+    COMBAT_LAUNCH(norm_bwd_fused_kernel,
                        dim3((C + 63) / 64, (unsigned)((px_per_group + chunk - 1) / chunk), groups), dim3(256), 0, st, a);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -982,7 +982,7 @@ extern "C" int combat_bn_eval_fold(const float *gamma, const float *beta, const 
                                    void *stream) {
     COMBAT_PLAN_HOOK(combat_bn_eval_fold, gamma, beta, running_mean, running_var, eps, C, scale, shift);
     if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(bn_eval_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta,
+    COMBAT_LAUNCH(bn_eval_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), gamma, beta,
                        running_mean, running_var, eps, C, scale, shift);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -992,7 +992,7 @@ extern "C" int combat_bn_eval_fold_batch(const combat_bn_desc *descs, int32_t n,
     COMBAT_PLAN_HOOK(combat_bn_eval_fold_batch, descs, n, eps);
     if (!descs || n < 0) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    hipLaunchKernelGGL(bn_eval_fold_batch_kernel, dim3(2, (unsigned)n), dim3(256), 0, as_stream(stream), descs, eps);
+    COMBAT_LAUNCH(bn_eval_fold_batch_kernel, dim3(2, (unsigned)n), dim3(256), 0, as_stream(stream), descs, eps);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -1002,7 +1002,7 @@ extern "C" int combat_group_stats(const void *x, int32_t groups, int32_t rows_pe
     COMBAT_PLAN_HOOK(combat_group_stats, x, groups, rows_per_group, C, partials);
     if (!x || !partials || groups <= 0 || rows_per_group <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     const long t = (long)groups * (C >> 3);
-    hipLaunchKernelGGL(group_stats_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(group_stats_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), (const __bf16 *)nullptr, groups, rows_per_group, C, 0,
                        (const float *)nullptr, (const float *)nullptr, partials);
     CB_LAUNCH_CHECK();
@@ -1016,7 +1016,7 @@ extern "C" int combat_group_stats_bwd(const void *dz, const void *x, int32_t gro
     if (!dz || !x || !partials || !xh_mean || !xh_rstd || parts_per_image < 0) return COMBAT_EINVAL;
     if (groups <= 0 || rows_per_group <= 0 || C <= 0 || (C & 7)) return COMBAT_EINVAL;
     const long t = (long)groups * (C >> 3);
-    hipLaunchKernelGGL(group_stats_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(group_stats_kernel, dim3((unsigned)((t + 255) / 256)), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(dz), groups,
                        rows_per_group, C, parts_per_image, xh_mean, xh_rstd, partials);
     CB_LAUNCH_CHECK();
@@ -1032,7 +1032,7 @@ extern "C" int combat_norm_bwd_apply(const void *dz, const void *x, const void *
     const long total = rows * (C >> 3);
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(norm_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+    COMBAT_LAUNCH(norm_bwd_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(dz), reinterpret_cast<const __bf16 *>(x),
                        reinterpret_cast<const __bf16 *>(add), reinterpret_cast<__bf16 *>(dx), (long)rows, C,
                        rows_per_group, grouped, ca, cb, cc);

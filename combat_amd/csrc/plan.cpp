@@ -9,9 +9,12 @@
 // data-parallel all-reduce mark, and at the end of the plan).
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <vector>
 
 #include "combat_hip.h"
+#include "common.hpp"
 #include "plan.hpp"
 
 struct combat_plan {
@@ -28,6 +31,11 @@ struct combat_plan {
     unsigned used = 0;                 // auxiliary queues with work not yet joined
     int failed = -1;                   // index of the call whose status combat_plan_run returned
 };
+
+namespace combat_launch {
+thread_local hipEvent_t t_stop = nullptr;
+thread_local bool t_stop_used = false;
+}  // namespace combat_launch
 
 namespace {
 thread_local combat_plan *t_plan = nullptr;
@@ -91,6 +99,12 @@ extern "C" int32_t combat_plan_failed_call(const combat_plan *p) { return p ? p-
 extern "C" int combat_plan_run(combat_plan *p, int32_t begin, int32_t end, void *stream, void *const *aux_streams, int32_t n_aux) {
     if (!p || begin < 0 || end > (int32_t)p->calls.size() || begin > end || n_aux < 0 || (n_aux && !aux_streams)) return COMBAT_EINVAL;
     hipStream_t main_st = reinterpret_cast<hipStream_t>(stream);
+    // Hand-off to an auxiliary queue: the aux call must see everything enqueued before it.  The cheap form: the plan-stream
+    // call right in front of it is launched with the hand-off event as its kernel's completion event (COMBAT_LAUNCH,
+    // common.hpp) -- nothing extra enters the plan's own queue.  Fallback (the call in front launched no kernel, or the
+    // aux call opens the range): an event record on the plan's stream.
+    static const bool record_always = getenv("COMBAT_HANDOFF_RECORD") && atoi(getenv("COMBAT_HANDOFF_RECORD")) == 1;
+    hipEvent_t carried = nullptr;     // completion event of the last plan-stream call, if it was launched with one
     for (int32_t i = begin; i < end; ++i) {
         const combat_plan::Call &c = p->calls[i];
         const bool on_aux = c.queue >= 0 && n_aux > 0;
@@ -102,14 +116,30 @@ extern "C" int combat_plan_run(combat_plan *p, int32_t begin, int32_t end, void 
         int rc;
         if (on_aux) {
             hipStream_t aux = reinterpret_cast<hipStream_t>(st_i);
-            hipEvent_t &ev = p->handoff[i];
-            if (!ev && !(ev = new_event())) return COMBAT_ELAUNCH;
+            hipEvent_t ev = carried;
+            if (!ev) {
+                hipEvent_t &own = p->handoff[i];
+                if (!own && !(own = new_event())) return COMBAT_ELAUNCH;
+                if (hipEventRecord(own, main_st) != hipSuccess) return COMBAT_ELAUNCH;
+                ev = own;
+            }
             // everything enqueued so far (the producers of this call's operands) happens-before it
-            if (hipEventRecord(ev, main_st) != hipSuccess || hipStreamWaitEvent(aux, ev, 0) != hipSuccess) return COMBAT_ELAUNCH;
+            if (hipStreamWaitEvent(aux, ev, 0) != hipSuccess) return COMBAT_ELAUNCH;
             rc = c.fn(st_i);
             p->used |= 1u << (c.queue % n_aux);
         } else {
+            const bool next_aux = !record_always && n_aux > 0 && i + 1 < end && p->calls[i + 1].queue >= 0;
+            hipEvent_t ev = nullptr;
+            if (next_aux) {
+                hipEvent_t &own = p->handoff[i + 1];
+                if (!own && !(own = new_event())) return COMBAT_ELAUNCH;
+                ev = own;
+                combat_launch::t_stop = ev;
+                combat_launch::t_stop_used = false;
+            }
             rc = c.fn(stream);
+            combat_launch::t_stop = nullptr;
+            carried = next_aux && combat_launch::t_stop_used ? ev : nullptr;
         }
         if (rc == COMBAT_OK && c.awaited && n_aux > 0) {
             hipEvent_t &ev = p->done[i];

@@ -435,7 +435,7 @@ extern "C" int combat_trigger_fwd(const float *x, const void *noise, const float
     if (n == 0) return COMBAT_OK;
     const int bytes = (4 * hw * hw + 2 * hw) * 4;
     if (set_smem(trigger_fwd_kernel, bytes)) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(trigger_fwd_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x,
+    COMBAT_LAUNCH(trigger_fwd_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x,
                        reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, src_index, out,
                        reinterpret_cast<__bf16 *>(out_c8), mse_partial);
     CB_LAUNCH_CHECK();
@@ -451,7 +451,7 @@ extern "C" int combat_trigger_bwd(const float *x, const void *noise, const float
     if (n == 0) return COMBAT_OK;
     const int bytes = (5 * hw * hw + 2 * hw) * 4;
     if (set_smem(trigger_bwd_kernel, bytes)) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(trigger_bwd_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x,
+    COMBAT_LAUNCH(trigger_bwd_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x,
                        reinterpret_cast<const __bf16 *>(noise), P, k1, noise_rate, hw, d_out, d_out2, out, l2_scale,
                        pre_tanh, reinterpret_cast<__bf16 *>(d_noise));
     CB_LAUNCH_CHECK();
@@ -464,14 +464,14 @@ extern "C" int combat_augment_fwd(const float *x, const int32_t *src_index, cons
     if (!x || !out_c8 || n < 0 || hw < 2 || hw > 1024) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     if (hw > 96) {
-        hipLaunchKernelGGL(augment_fwd_big_kernel, dim3((hw * hw + 255) / 256, n), dim3(256), 0, as_stream(stream), x, src_index,
+        COMBAT_LAUNCH(augment_fwd_big_kernel, dim3((hw * hw + 255) / 256, n), dim3(256), 0, as_stream(stream), x, src_index,
                            params, hw, reinterpret_cast<uint4 *>(out_c8), out_f32);
         CB_LAUNCH_CHECK();
         return COMBAT_OK;
     }
     const int bytes = 3 * hw * hw * 4;
     if (set_smem(augment_fwd_kernel, bytes)) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(augment_fwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), x, src_index, params, hw,
+    COMBAT_LAUNCH(augment_fwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), x, src_index, params, hw,
                        reinterpret_cast<uint4 *>(out_c8), out_f32);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -485,14 +485,14 @@ extern "C" int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const f
     if (hw > 96) {
         hipStream_t st = as_stream(stream);
         if (!accumulate && hipMemsetAsync(d_x, 0, (size_t)n * 3 * hw * hw * sizeof(float), st) != hipSuccess) return COMBAT_ELAUNCH;
-        hipLaunchKernelGGL(augment_bwd_big_kernel, dim3((hw * hw + 255) / 256, n), dim3(256), 0, st,
+        COMBAT_LAUNCH(augment_bwd_big_kernel, dim3((hw * hw + 255) / 256, n), dim3(256), 0, st,
                            reinterpret_cast<const __bf16 *>(d_c8), c8_channels, params, hw, d_x);
         CB_LAUNCH_CHECK();
         return COMBAT_OK;
     }
     const int bytes = 3 * hw * hw * 4;
     if (set_smem(augment_bwd_kernel, bytes)) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(augment_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream),
+    COMBAT_LAUNCH(augment_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(d_c8), c8_channels, params, hw, d_x, accumulate);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -503,14 +503,14 @@ extern "C" int combat_dct_u8(const float *x, const float *D, int32_t n, int32_t 
     if (!x || !D || !out_c8 || n < 0 || hw < 4 || hw > 256 || (hw & 3) || (hw > 64 && (hw & 15))) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
     if (hw > 64) {
-        hipLaunchKernelGGL(dct_u8_big_kernel, dim3(hw / 16, 3, n), dim3(256), 2 * 16 * hw * 4, as_stream(stream), x, D, hw,
+        COMBAT_LAUNCH(dct_u8_big_kernel, dim3(hw / 16, 3, n), dim3(256), 2 * 16 * hw * 4, as_stream(stream), x, D, hw,
                            reinterpret_cast<__bf16 *>(out_c8));
         CB_LAUNCH_CHECK();
         return COMBAT_OK;
     }
     const int bytes = (4 * hw * hw + 2 * hw) * 4;
     if (set_smem(dct_u8_kernel, bytes)) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(dct_u8_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x, D, hw,
+    COMBAT_LAUNCH(dct_u8_kernel, dim3(3, n), dim3(256), bytes, as_stream(stream), x, D, hw,
                        reinterpret_cast<__bf16 *>(out_c8));
     CB_LAUNCH_CHECK();
     return COMBAT_OK;

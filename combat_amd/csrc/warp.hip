@@ -212,7 +212,7 @@ extern "C" int combat_grid_head_fwd(const float *fc1_bias, const float *fc2_weig
                                     int32_t nout, float *field, void *stream) {
     COMBAT_PLAN_HOOK(combat_grid_head_fwd, fc1_bias, fc2_weight, fc2_bias, nf, nout, field);
     if (!fc1_bias || !fc2_weight || !fc2_bias || !field || nf <= 0 || nf > kMaxNf || nout <= 0 || nout > kMaxField) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(grid_head_fwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), fc1_bias, fc2_weight, fc2_bias, nf, nout, field);
+    COMBAT_LAUNCH(grid_head_fwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), fc1_bias, fc2_weight, fc2_bias, nf, nout, field);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }
@@ -221,7 +221,7 @@ extern "C" int combat_wanet_grid(const float *field, const float *U, int32_t S, 
                                  float *grid, void *stream) {
     COMBAT_PLAN_HOOK(combat_wanet_grid, field, U, S, H, rescale, noise_grid, grid);
     if (!field || !U || !noise_grid || !grid || S < 1 || 2 * S * S > kMaxField || H < 2) return COMBAT_EINVAL;
-    hipLaunchKernelGGL(wanet_grid_kernel, dim3((H * H + 255) / 256), dim3(256), 0, as_stream(stream), field, U, S, H, rescale,
+    COMBAT_LAUNCH(wanet_grid_kernel, dim3((H * H + 255) / 256), dim3(256), 0, as_stream(stream), field, U, S, H, rescale,
                        noise_grid, grid);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -232,7 +232,7 @@ extern "C" int combat_warp_fwd(const float *x, const int32_t *src_index, const f
     COMBAT_PLAN_HOOK(combat_warp_fwd, x, src_index, grid, per_image_grid, n, H, out);
     if (!x || !grid || !out || n < 0 || H < 2) return COMBAT_EINVAL;
     if (n == 0) return COMBAT_OK;
-    hipLaunchKernelGGL(warp_fwd_kernel, dim3((H * H + 255) / 256, n), dim3(256), 0, as_stream(stream), x, src_index, grid,
+    COMBAT_LAUNCH(warp_fwd_kernel, dim3((H * H + 255) / 256, n), dim3(256), 0, as_stream(stream), x, src_index, grid,
                        per_image_grid ? (long)H * H * 2 : 0L, H, out);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -243,7 +243,7 @@ extern "C" int combat_warp_bwd(const float *x, const float *d_out, const float *
     COMBAT_PLAN_HOOK(combat_warp_bwd, x, d_out, d_out2, grid, per_image_grid, n, H, groups, partial);
     if (!x || !d_out || !grid || !partial || n <= 0 || H < 2 || groups < 1) return COMBAT_EINVAL;
     const int per = (n + groups - 1) / groups;
-    hipLaunchKernelGGL(warp_bwd_kernel, dim3((H * H + 255) / 256, groups), dim3(256), 0, as_stream(stream), x, d_out, d_out2, grid,
+    COMBAT_LAUNCH(warp_bwd_kernel, dim3((H * H + 255) / 256, groups), dim3(256), 0, as_stream(stream), x, d_out, d_out2, grid,
                        per_image_grid ? (long)H * H * 2 : 0L, n, per, H, partial);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -256,7 +256,7 @@ extern "C" int combat_warp_bwd_input(const float *d_out, const float *grid, int3
     if (n == 0) return COMBAT_OK;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(d_x, 0, (size_t)n * 3 * H * H * sizeof(float), st) != hipSuccess) return COMBAT_ELAUNCH;
-    hipLaunchKernelGGL(warp_bwd_input_kernel, dim3((H * H + 255) / 256, n), dim3(256), 0, st, d_out, grid,
+    COMBAT_LAUNCH(warp_bwd_input_kernel, dim3((H * H + 255) / 256, n), dim3(256), 0, st, d_out, grid,
                        per_image_grid ? (long)H * H * 2 : 0L, H, d_x);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
@@ -274,10 +274,10 @@ extern "C" int combat_wanet_field_bwd(const float *partial, int32_t groups, cons
                    rescale, l2_scale, d_fc1_bias, d_fc2_weight, d_fc2_bias, d_field};
     hipStream_t st = as_stream(stream);
     switch (S) {
-        case 1: hipLaunchKernelGGL(wanet_field_bwd_kernel<1>, dim3(1), dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL(wanet_field_bwd_kernel<2>, dim3(1), dim3(256), 0, st, a); break;
-        case 3: hipLaunchKernelGGL(wanet_field_bwd_kernel<3>, dim3(1), dim3(256), 0, st, a); break;
-        default: hipLaunchKernelGGL(wanet_field_bwd_kernel<4>, dim3(1), dim3(256), 0, st, a); break;
+        case 1: COMBAT_LAUNCH(wanet_field_bwd_kernel<1>, dim3(1), dim3(256), 0, st, a); break;
+        case 2: COMBAT_LAUNCH(wanet_field_bwd_kernel<2>, dim3(1), dim3(256), 0, st, a); break;
+        case 3: COMBAT_LAUNCH(wanet_field_bwd_kernel<3>, dim3(1), dim3(256), 0, st, a); break;
+        default: COMBAT_LAUNCH(wanet_field_bwd_kernel<4>, dim3(1), dim3(256), 0, st, a); break;
     }
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
