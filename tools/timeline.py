@@ -1,7 +1,7 @@
 """Kernel timeline of ONE steady-state alternated step (torch.profiler chrome trace): every launch with its queue, start,
 duration and the idle time in front of it on its own queue -- where the critical queue waits for another one.
 
-    python tools/timeline.py [out.txt]      (default gpurun_out/timeline.txt; summary on stdout)
+    [TL_BS=32] python tools/timeline.py [out.txt]      (default gpurun_out/timeline.txt; summary on stdout)
 """
 import collections
 import json
@@ -21,8 +21,11 @@ out_path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/timeline.txt"
 dev = torch.device("cuda", 0)
 np.random.seed(0)
 torch.manual_seed(0)
-st = step_mod.AlternatedStep(*bench.build_nets(dev), bench.Opt())
-batches = bench.synth_batches(8, 128, 0, dev)
+BS = int(os.environ.get("TL_BS", "128"))
+opt = bench.Opt()
+opt.bs = BS
+st = step_mod.AlternatedStep(*bench.build_nets(dev), opt)
+batches = bench.synth_batches(8, BS, 0, dev)
 for i in range(12):
     st.run(*batches[i % 8])
 torch.cuda.synchronize()
