@@ -146,7 +146,7 @@ SIGNATURES = {
 TILE_128x128, TILE_128x64, TILE_64x64, TILE_128x16, TILE_64x128 = 1, 2, 3, 4, 5
 TILE_H256x64, TILE_H128x128, TILE_H128x64, TILE_H64x64, TILE_D128x64, TILE_D128x32 = 6, 7, 8, 9, 10, 11
 TILE_G128x64, TILE_G128x32 = 12, 13
-TILE_D256x64, TILE_C8, TILE_D256W64, TILE_S128x64 = 14, 15, 16, 17
+TILE_D256x64, TILE_C8, TILE_D256W64, TILE_S128x64, TILE_K8 = 14, 15, 16, 17, 18
 STATS_PER_WORKGROUP = 4     # | into ConvArgs.stats_kind: one statistics row per workgroup (include/combat_hip.h)
 
 

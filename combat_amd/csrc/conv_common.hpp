@@ -16,6 +16,8 @@ int conv_gather_dma_bn(const combat_conv_args *a);                 // 0 (not app
 bool conv_gather_dma_parity_split(const combat_conv_args *a);      // statistics rows not image-aligned
 bool conv_c8_ok(const combat_conv_args *a);
 int conv_c8_launch(const combat_conv_args *a, hipStream_t st);
+bool conv_k8_ok(const combat_conv_args *a);      // conv_k8.hip: eight OUTPUT channels
+int conv_k8_launch(const combat_conv_args *a, hipStream_t st);
 int conv_gather_dma_launch(const combat_conv_args *a, hipStream_t st);
 int conv_gather_dma_pair_launch(const combat_conv_args *a, const combat_conv_args *b, hipStream_t st);   // 1: not groupable
 long conv_gather_dma_workspace(const combat_conv_args *a);        // scratch bytes a split reduction would use

@@ -595,7 +595,7 @@ __device__ __forceinline__ void conv_c8_body(const GatherParams &p) {
 }
 
 #ifndef COMBAT_C8_WAVES
-#define COMBAT_C8_WAVES 3
+#define COMBAT_C8_WAVES 2
 #endif
 __global__ __launch_bounds__(256, COMBAT_C8_WAVES) void conv_c8_kernel(const GatherParams p) { conv_c8_body<64>(p); }
 

@@ -22,6 +22,7 @@
 // normalisation/activation/residual element-wise ops around them.
 #include "conv_common.hpp"
 #include "plan.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -318,6 +319,8 @@ int pick_tile(const combat_conv_args *a) {
         return 0;   // a 3x3 tile was forced but does not apply
     if ((a->tile == 0 || a->tile == COMBAT_TILE_C8) && conv_c8_ok(a)) return COMBAT_TILE_C8;
     if (a->tile == COMBAT_TILE_C8) return 0;
+    if ((a->tile == COMBAT_TILE_K8 || (a->tile == 0 && !getenv("COMBAT_NO_K8"))) && conv_k8_ok(a)) return COMBAT_TILE_K8;
+    if (a->tile == COMBAT_TILE_K8) return 0;
     if (a->tile == 0 || a->tile >= COMBAT_TILE_G128x64) {   // prologue-free: operands by DMA
         const int bn = conv_gather_dma_bn(a);
         if (bn) return bn == 64 ? COMBAT_TILE_G128x64 : COMBAT_TILE_G128x32;
@@ -354,6 +357,7 @@ extern "C" int combat_conv_stats_granule(int tile) {
         case COMBAT_TILE_G128x64:
         case COMBAT_TILE_G128x32:
         case COMBAT_TILE_C8:
+        case COMBAT_TILE_K8:
         case COMBAT_TILE_D256W64:
         case COMBAT_TILE_S128x64:
         case COMBAT_TILE_D256x64: return 32;
@@ -448,6 +452,7 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     hipStream_t st = as_stream(stream);
     const int tile = pick_tile(a);
     if (tile == COMBAT_TILE_C8) return conv_c8_launch(a, st);
+    if (tile == COMBAT_TILE_K8) return conv_k8_launch(a, st);
     if (tile == COMBAT_TILE_G128x64 || tile == COMBAT_TILE_G128x32) return conv_gather_dma_launch(a, st);
     if (tile == COMBAT_TILE_D256W64 || tile == COMBAT_TILE_S128x64) return conv3x3_launch(a, tile, st);
     if (tile >= COMBAT_TILE_H256x64) return conv3x3_launch(a, tile, st);

@@ -140,6 +140,7 @@ typedef struct combat_conv_args {
 #define COMBAT_TILE_D256x64 14   /* conv3x3_dma with 256-pixel tiles (eight waves): large layers */
 #define COMBAT_TILE_C8 15        /* 3x3 over C = 8 (c8 images, 3-channel gradients): operands straight into the MFMA registers */
 #define COMBAT_TILE_S128x64 17   /* conv3x3 for C = K = 64, weight-stationary + persistent: the filter bank stays in LDS, 128-pixel tiles (statistics rows as D128x64) */
+#define COMBAT_TILE_K8 18        /* 3x3 stride 1 with eight OUTPUT channels (generator output layer, stem input gradient): patch through registers with the prologue, weights in registers (conv_k8.hip) */
 #define COMBAT_TILE_D256W64 16   /* conv3x3_dma, 256-pixel tiles as four waves of 64 pixels x 64 channels (16-wide maps, >= 16 rows) */
 
 int combat_conv_gemm(const combat_conv_args *a, void *stream);

@@ -469,6 +469,62 @@ def test_conv_forward_instnorm_leaky_bias_tanh(ops):
     assert float(out[:, 3:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,hw,c", [(5, 16, 64), (3, 32, 64), (2, 32, 128), (2, 64, 64)])
+def test_conv_eight_output_channels_kernel(ops, n, hw, c):
+    """COMBAT_TILE_K8 (conv_k8.hip): 3x3 stride-1 convolutions into the 8-channel image layout -- the generator's output
+    layer (per-(image, channel) InstanceNorm affine + LeakyReLU(0.2) prologue, bias, tanh; also with a per-channel
+    prologue and with none) and a stem's input gradient (mode 1 over a 64-channel dY) -- against the generic 16-wide
+    tile on the same arguments and against torch; it is the automatic choice for these launches."""
+    from combat_amd._lib import lib, TILE_K8
+    import ctypes
+    x = torch.randn(n, c, hw, hw, generator=g(401))
+    w = torch.randn(3, c, 3, 3, generator=g(402)) * 0.05
+    b = torch.randn(3, generator=g(403)) * 0.1
+    pc = ops.PackedConv(dev(w).contiguous(memory_format=torch.channels_last), 1, 1, c)
+    pc.pack()
+    b8 = torch.zeros(8)
+    b8[:3] = b
+    sc_i, sh_i = torch.rand(n, c, generator=g(404)) + 0.5, torch.randn(n, c, generator=g(405)) * 0.3
+    sc_c, sh_c = torch.rand(c, generator=g(406)) + 0.5, torch.randn(c, generator=g(407)) * 0.3
+    cases = {
+        "instance prologue + bias + tanh": (dict(pro=ops.Affine(dev(sc_i), dev(sh_i), c, True, 0.2), bias=dev(b8), tanh_out=True),
+                                            lambda: torch.tanh(F.conv2d(rb(F.leaky_relu(rb(x) * sc_i[:, :, None, None] + sh_i[:, :, None, None], 0.2)), rb(w), b, padding=1))),
+        "channel prologue, no activation": (dict(pro=ops.Affine(dev(sc_c), dev(sh_c), 0, False, 0.0)),
+                                            lambda: F.conv2d(rb(rb(x) * sc_c[None, :, None, None] + sh_c[None, :, None, None]), rb(w), padding=1)),
+        "plain + bias": (dict(bias=dev(b8)), lambda: F.conv2d(rb(x), rb(w), b, padding=1)),
+    }
+    for name, (kw, ref) in cases.items():
+        outs = []
+        for tile in (TILE_K8, 4, 0):
+            y = torch.full((n, hw, hw, 8), 9.0, dtype=bf16, device="cuda")
+            a = ops.conv_args(nhwc(x), y, pc, 0, tile=tile, **kw)
+            assert lib.combat_conv_pick_tile(ctypes.byref(a)) == (tile or TILE_K8), name
+            ops.conv_launch(a)
+            outs.append(nchw(y))
+        assert rel_l2(outs[0][:, :3], ref()) < 4e-3, name
+        assert rel_l2(outs[0], outs[1]) < 2e-3, name
+        assert float(outs[0][:, 3:].abs().max()) == 0.0 and torch.equal(outs[0], outs[2]), name
+    # a stem's input gradient: dY with c channels -> the 3 (of 8) image channels, taps mirrored
+    ws, pcs = make_conv(ops, c, 3, 3, 1, 1, 408, c_pad=8)
+    dy = torch.randn(n, c, hw, hw, generator=g(409))
+    outs = []
+    for tile in (TILE_K8, 4, 0):
+        dx = torch.full((n, hw, hw, 8), 9.0, dtype=bf16, device="cuda")
+        a = ops.conv_args(nhwc(dy), dx, pcs, 1, tile=tile)
+        assert lib.combat_conv_pick_tile(ctypes.byref(a)) == (tile or TILE_K8)
+        ops.conv_launch(a)
+        outs.append(nchw(dx))
+    gin = torch.nn.grad.conv2d_input((n, 3, hw, hw), rb(ws), rb(dy), padding=1)
+    assert rel_l2(outs[0][:, :3], gin) < 4e-3 and rel_l2(outs[0], outs[1]) < 2e-3 and torch.equal(outs[0], outs[2])
+    assert float(outs[0][:, 3:].abs().max()) == 0.0
+    # what it does not cover stays with the general kernels: a residual operand, a ragged tile grid
+    y = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+    a = ops.conv_args(nhwc(x), y, pc, 0, add_post=y)
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) != TILE_K8
+    a = ops.conv_args(nhwc(x[:, :, :12, :12].contiguous()), torch.empty(n, 12, 12, 8, dtype=bf16, device="cuda"), pc, 0)
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) != TILE_K8
+
+
 def test_conv_forward_hilo_stem(ops):
     """3-channel image as c8 hi/lo split: the stem sees ~16 mantissa bits of the pixels."""
     n, hw = 4, 32

@@ -1,5 +1,5 @@
-"""The generator's output layer (upconv0_0: 64 -> 3 (stored as 8), 32x32, InstanceNorm + LeakyReLU prologue, tanh) and the
-input gradient of that layer (8 -> 64 with mask): time per tile id, N = 128."""
+"""The generator's output layer (upconv0_0: 64 -> 3 (stored as 8), 32x32, InstanceNorm + LeakyReLU prologue, tanh) and a
+stem's input gradient (64-channel dY -> 8): time per tile id (18 = conv_k8, 4 = the generic 16-wide tile), N = 128."""
 import math, os, sys, ctypes
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,7 @@ y = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
 sc, sh = torch.rand(n, c, device="cuda") + 0.5, torch.randn(n, c, device="cuda")
 pro = ops.Affine(sc, sh, c, True, 0.2)
 bias = torch.zeros(8, device="cuda")
-for tile in (0, 2, 3, 4, 6, 8, 9):
+for tile in (0, 18, 4, 2):
     try:
         a = ops.conv_args(x, y, pc, 0, pro=pro, bias=bias, tanh_out=True, tile=tile)
         picked = lib.combat_conv_pick_tile(ctypes.byref(a))
@@ -24,3 +24,11 @@ for tile in (0, 2, 3, 4, 6, 8, 9):
         print("fwd  tile %d -> %d: b2b %.1f / iso %.1f / cold %.1f us" % (tile, picked, b2b, iso, cold), flush=True)
     except Exception as e:
         print("fwd  tile %d: n/a (%s)" % (tile, str(e)[:60]))
+ws = (torch.randn(c, 3, 3, 3, device="cuda") / math.sqrt(27)).contiguous(memory_format=torch.channels_last)
+pcs = ops.PackedConv(ws, 1, 1, 8)
+pcs.pack()
+for tile in (0, 18, 4):
+    a = ops.conv_args(x, y, pcs, 1, tile=tile)
+    picked = lib.combat_conv_pick_tile(ctypes.byref(a))
+    b2b, iso, cold = cb.timeit(a)
+    print("stem dgrad tile %d -> %d: b2b %.1f / iso %.1f / cold %.1f us" % (tile, picked, b2b, iso, cold), flush=True)
