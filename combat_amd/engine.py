@@ -1362,21 +1362,30 @@ class UnetEngine(NetEngine):
         G = lambda name, like: slot.buf("g." + name, like.shape)
         P.add("zero_grad", _zero_grad_call, fp)
         gz = slot.buf("g.z", (n, hw, hw, 8))
-        P.add("db.upconv0_0", lib.combat_colsum, gz.data_ptr(), n * hw * hw, 8, 3,
-              fp.grad_phys("upconv0_0.bias").data_ptr(), aux=True)
 
-        def through_norm(name, dy, pcv, src_name, add_pre=None):
+        def through_norm(name, dy, pcv, src_name, add_pre=None, first=False):
             """dy = gradient w.r.t. raw output of conv `pcv` whose input is LR(IN(t[src_name])).
-            wgrad of pcv, then gradient w.r.t. t[src_name] (returned)."""
+            wgrad of pcv, then gradient w.r.t. t[src_name] (returned).  first: the plan's first layer -- its auxiliary
+            calls are recorded BEHIND its input-gradient launch, so that they are handed the plan stream's state by that
+            launch's completion event: an auxiliary call that opens a plan needs an event record in the plan's queue,
+            which held the first kernel of the generator's backward back by ~20 us (tools/timeline.py)."""
             src, st = t(src_name), stn(src_name)
             act = slot.bufs.get("a." + name)   # LR(IN(src)) of the forward (all but the K = 8 output layer)
-            if act is not None:
-                rec_wgrad(P, name + ".wgrad", act, dy, pcv, fp.grad_phys(name + ".weight"))
-            else:
-                rec_wgrad(P, name + ".wgrad", src, dy, pcv, fp.grad_phys(name + ".weight"), self._in_aff(st))
+
+            def wgrad():
+                if act is not None:
+                    rec_wgrad(P, name + ".wgrad", act, dy, pcv, fp.grad_phys(name + ".weight"))
+                else:
+                    rec_wgrad(P, name + ".wgrad", src, dy, pcv, fp.grad_phys(name + ".weight"), self._in_aff(st))
+            if not first:
+                wgrad()
             dz = G(src_name + ".dz", src)
             self._dgrad_norm(P, slot, "g." + src_name, dy, dz, pcv, src, st, group_stride=st.C, slope=self.LR,
                              add_pre=add_pre)
+            if first:
+                P.add("db.upconv0_0", lib.combat_colsum, gz.data_ptr(), n * hw * hw, 8, 3,
+                      fp.grad_phys("upconv0_0.bias").data_ptr(), aux=True)
+                wgrad()
             dx = G(src_name + ".dx", src)
             self._bwd_apply(P, slot, "g." + src_name, dz, src, dx, st)
             return dx
@@ -1403,7 +1412,7 @@ class UnetEngine(NetEngine):
             self._bwd_apply(P, slot, "g." + y_name, du, y, dy_out, st)    # sums taken from du / y directly
             return du, dy_out
 
-        d = through_norm("upconv0_0", gz, pc["upconv0_0"], "upconv0_1")
+        d = through_norm("upconv0_0", gz, pc["upconv0_0"], "upconv0_1", first=True)
         du0, d = through_up("upconv0_1", d, pc["upconv0_1"], 0, "upconv1_0")
         d = through_norm("upconv1_0", d, pc["upconv1_0"], "upconv1_1")
         du1, d = through_up("upconv1_1", d, pc["upconv1_1"], 1, "upconv2_0")
