@@ -303,7 +303,11 @@ def _aux_stream(parent: torch.cuda.Stream, k: int = 0) -> torch.cuda.Stream:
     key = (parent.device, parent.cuda_stream, k)
     s = _AUX_STREAMS.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=parent.device)
+        if os.environ.get("COMBAT_LOW_PRIO_SIDE", "0") == "1":
+            from .step import low_priority_stream
+            s = low_priority_stream(parent.device)
+        else:
+            s = torch.cuda.Stream(device=parent.device)
         _AUX_STREAMS[key] = s
     return s
 

@@ -110,9 +110,28 @@ def shared_stream(device, kind: str, priority: int = 0) -> torch.cuda.Stream:
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), kind)
     s = _STREAMS.get(key)
     if s is None:
-        s = torch.cuda.Stream(device=dev, priority=priority)
+        s = low_priority_stream(dev) if (kind != "main" and LOW_PRIO_SIDE) else torch.cuda.Stream(device=dev, priority=priority)
         _STREAMS[key] = s
     return s
+
+
+LOW_PRIO_SIDE = os.environ.get("COMBAT_LOW_PRIO_SIDE", "0") == "1"   # experiment: second / auxiliary queues below the critical one
+_HIP = None
+
+
+def low_priority_stream(dev) -> torch.cuda.Stream:
+    """A stream of the LOWEST priority the device offers (torch only exposes normal / high)."""
+    import ctypes
+    global _HIP
+    if _HIP is None:
+        _HIP = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(), ctypes.c_int()
+    assert _HIP.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        assert _HIP.hipStreamCreateWithPriority(ctypes.byref(h), 1, least.value) == 0      # 1 = hipStreamNonBlocking
+    print("low-priority stream: range least %d greatest %d" % (least.value, greatest.value), flush=True)
+    return torch.cuda.ExternalStream(h.value, device=dev)
 
 
 FORCE_ALLREDUCE = os.environ.get("COMBAT_FORCE_ALLREDUCE", "0") == "1"   # issue the bucketed all-reduces even at world size 1
