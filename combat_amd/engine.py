@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import STATS_PER_WORKGROUP, CombatHipError, lib
+from ._lib import STATS_PER_WORKGROUP, TILE_D128x64, TILE_S128x64, CombatHipError, lib
 from .nets import UNET_LAYERS
 from .ops import Affine, PackedConv, bf16
 
@@ -448,8 +448,32 @@ def _zero_grad_call(fp, st):
     return lib.combat_memset_zero(fp.grad.data_ptr(), fp.total * 4, st)
 
 
+_SHORT_WORKGROUPS = False
+
+
+class short_workgroups:
+    """Plans recorded inside this context keep to one tile per workgroup: the weight-stationary persistent kernel
+    (COMBAT_TILE_S128x64) is replaced by the ring kernel on the same tiles.  For passes that run BESIDE the critical
+    queue: a persistent workgroup holds its CU (and 141 KB of its LDS) for 4-8 tiles, 17-34 us at 128-256 images, and
+    the critical queue's launches wait for CUs that long."""
+
+    def __enter__(self):
+        global _SHORT_WORKGROUPS
+        self.prev, _SHORT_WORKGROUPS = _SHORT_WORKGROUPS, True
+
+    def __exit__(self, *exc):
+        global _SHORT_WORKGROUPS
+        _SHORT_WORKGROUPS = self.prev
+
+
+def _tile_preference(a) -> None:
+    if _SHORT_WORKGROUPS and a.tile == 0 and lib.combat_conv_pick_tile(ctypes.byref(a)) == TILE_S128x64:
+        a.tile = TILE_D128x64
+
+
 def rec_conv(plan: Plan, what: str, src, dst, pc: PackedConv, mode: int, **kw):
     a = ops.conv_args(src, dst, pc, mode, workspace=plan.workspace(src.device), **kw)
+    _tile_preference(a)
     plan.hold(a)
     plan.add(what, lib.combat_conv_gemm, ctypes.byref(a))
     return a
@@ -617,6 +641,7 @@ class NetEngine:
         n, p, q, c = dst.shape
         pq, m = p * q, n * p * q
         a = ops.conv_args(src, dst, pc, 0, workspace=plan.workspace(src.device), **conv_kw)
+        _tile_preference(a)
         a.stats_kind = 1 | (BATCH_STATS_ROWS if groups == 1 else 0)    # (the row layout depends on it)
         rows, rpi = ops.conv_stats_layout(a)
         fused = (groups == 1) or (rpi > 0)
@@ -677,6 +702,7 @@ class NetEngine:
         groups = st.groups
         mask = Affine(st.scale, st.shift, group_stride, True, slope)
         a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask, workspace=plan.workspace(dy.device))
+        _tile_preference(a)
         a.stats_kind = 2 | (BATCH_STATS_ROWS if groups == 1 else 0)
         a.xh_mean, a.xh_rstd = st.mean.data_ptr(), st.rstd.data_ptr()
         rows, rpi = ops.conv_stats_layout(a)

@@ -15,6 +15,7 @@ kernel launches with no host synchronisation; metric counters stay on the device
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -28,7 +29,7 @@ from . import ops, trigger
 from ._lib import lib
 from .augment import PostTensorTransform
 from .dist import GradReducer, bucket_ranges
-from .engine import FreqEngine, PreActEngine, UnetEngine, f32
+from .engine import FreqEngine, PreActEngine, UnetEngine, f32, short_workgroups
 
 BUCKETS = (8, 16, 32, 64, 128, 256, 512, 1024)
 
@@ -134,6 +135,7 @@ def low_priority_stream(dev) -> torch.cuda.Stream:
     return torch.cuda.ExternalStream(h.value, device=dev)
 
 
+SIDE_SHORT_WORKGROUPS = os.environ.get("COMBAT_SIDE_WS", "0") != "1"   # (COMBAT_SIDE_WS=1: A/B, the persistent kernel on the second stream too)
 FORCE_ALLREDUCE = os.environ.get("COMBAT_FORCE_ALLREDUCE", "0") == "1"   # issue the bucketed all-reduces even at world size 1
 #                                                                          (tests: RCCL's streams beside the step's on ONE GPU)
 
@@ -261,16 +263,18 @@ class AlternatedStep:
         self.pl = dict(
             C_train_f=eC.forward_plan(self.sC_train, True), C_train_b=eC.backward_train_plan(self.sC_train),
             C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False),
-            C_met_f=eC.forward_plan(self.sC_met, False, 1.0, False),
-            K_eval_f=eK.forward_plan(self.sK_eval, False, w_cm, True, split_head=True),
         )
         self.pl.update(self._gen_plans())
         self.sC_bd = self.sC_eval
-        self.sK_bd = self.sK_eval.half_view(n, n, eK.FWD_SHARED)
         self.pl["C_bd_b"] = eC.backward_eval_plan(self.sC_bd, 1.0)
-        self.pl["K_bd_b"] = eK.backward_eval_plan(self.sK_bd, w_cm)
-        if self.sF is not None:
-            self.pl["F_f"] = self.eF.forward_plan(self.sF)
+        # the second stream's passes run beside the critical queue: one tile per workgroup (engine.short_workgroups)
+        with (short_workgroups() if SIDE_SHORT_WORKGROUPS else contextlib.nullcontext()):
+            self.pl["C_met_f"] = eC.forward_plan(self.sC_met, False, 1.0, False)
+            self.pl["K_eval_f"] = eK.forward_plan(self.sK_eval, False, w_cm, True, split_head=True)
+            self.sK_bd = self.sK_eval.half_view(n, n, eK.FWD_SHARED)
+            self.pl["K_bd_b"] = eK.backward_eval_plan(self.sK_bd, w_cm)
+            if self.sF is not None:
+                self.pl["F_f"] = self.eF.forward_plan(self.sF)
 
     def _gen_slot(self, n):
         return self.eG.slot("G", n, self.hw)
