@@ -142,7 +142,11 @@ def conv_flops(a):
     with the REAL channel counts (padding channels and the masked taps of a strided dgrad are not work)."""
     pc = a._keepalive[2]
     pix = a.N * a.P * a.Q if a.mode == 0 else a.N * a.H * a.W
-    return 2.0 * pix * pc.K * pc.c_real * pc.taps
+    fl = 2.0 * pix * pc.K * pc.c_real * pc.taps
+    if a.src2:      # the block's 1x1 shortcut rides along (combat_conv_args.src2): its input gradient's work too
+        pc2 = a._keepalive[-1][1]
+        fl += 2.0 * pix * pc2.K * pc2.c_real * pc2.taps
+    return fl
 
 
 def wgrad_flops(a):
@@ -234,7 +238,9 @@ def roofline_from(prof):
                            for t, (f, s_, c) in sorted(groups.items())},
         "per_shape": shapes,
         "per_shape_note": "PreActResNet18 convolutions (surrogate + clean model plans), keyed 'RxS stride Cin->Cout "
-                          "@input HxW'; wgrad = weight-gradient launch incl. its partial-sum reduction launch",
+                          "@input HxW'; wgrad = weight-gradient launch incl. its partial-sum reduction launch; the 1x1 "
+                          "stride-2 shortcuts' input gradients ride along in the 3x3 stride-2 dgrad launches (second "
+                          "reduction source), their FLOPs are counted there",
     }
 
 

@@ -33,6 +33,7 @@ class ConvArgs(C.Structure):
         ("act_dst", c_vp), ("act_scale", c_vp), ("act_shift", c_vp), ("act_slope", c_f32),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
         ("tile", c_i32),
+        ("src2", c_vp), ("wpack2", c_vp), ("kpad2", c_i32), ("rows_pad2", c_i32),
     ]
 
 

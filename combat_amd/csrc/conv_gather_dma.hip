@@ -37,6 +37,8 @@ struct GatherParams {
     int flavour;                 // epilogue specialisation (conv_dma_epilogue.hpp), -1: generic
     int block_base;              // first workgroup of this problem in the launch (0 unless it is the second of a pair)
     int w_prefetch;              // warm the XCD's L2 with this workgroup's weight rows at kernel start (conv3x3_dma.hip)
+    int cpt2;                    // > 0: 64-channel chunks of the second reduction source (a.src2 / a.wpack2: the shortcut's
+    unsigned w2_bytes;           //      input gradient as extra steps on the centre tap's pixels), bytes of its operand
     unsigned long long *stamps;  // profiling builds only (-DCOMBAT_STAMPS): per workgroup, cycles per phase
 };
 
@@ -114,7 +116,13 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
     using std::integral_constant;
-    const int nsteps_all = ntap * p.cpt;
+    // second source (a residual block's 1x1 / stride-2 shortcut, input gradient): its pixels are those of the 3x3's
+    // centre tap, so its chunks are cpt2 more reduction steps "tap index ntap" -- in parity-class-major order only the
+    // (even, even) class reaches them, otherwise the centre tap's validity bit decides per pixel
+    const bool has2 = p.cpt2 > 0 && (!p.psplit || pcls == 0);
+    const __amdgpu_buffer_rsrc_t srsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src2), 0, has2 ? p.src_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack2), 0, has2 ? p.w2_bytes : 0u, 0x00020000);
+    const int nsteps_all = ntap * p.cpt + (has2 ? p.cpt2 : 0);
     int g_lo = 0, nsteps = nsteps_all;
     if (p.splits > 1) {
         const int per = (nsteps_all + p.splits - 1) / p.splits;
@@ -131,15 +139,27 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
             ++j_;
         }
     };
-    auto tap_of = [&](int j_) __attribute__((always_inline)) { return p.psplit ? (taplist >> (4 * j_)) & 15 : j_; };
-    unsigned wvoff[WPW];
+    auto tap_of = [&](int j_) __attribute__((always_inline)) {
+        if (j_ >= ntap) return 4;      // the second source's steps: addressed as the centre tap
+        return p.psplit ? (taplist >> (4 * j_)) & 15 : j_;
+    };
+    unsigned wvoff[WPW], wvoff2[WPW];
 #pragma unroll
     for (int j = 0; j < WPW; ++j) {
         const int n = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
         wvoff[j] = (unsigned)(((n0 + n) * a.kpad + ((slot - (n & 6)) & 7) * 8) * 2);
+        wvoff2[j] = (unsigned)(((n0 + n) * a.kpad2 + ((slot - (n & 6)) & 7) * 8) * 2);
     }
     auto issue_w = [&](int j_, int cc, auto stage_tag) __attribute__((always_inline)) {
         constexpr int sbase = decltype(stage_tag)::value * SBYTES;
+        if (j_ >= ntap) {              // (uniform) the shortcut's operand: one tap, k = channel
+            const int soff = cc * 64 * 2;
+#pragma unroll
+            for (int j = 0; j < WPW; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc2, (lds_void_t *)(smem + sbase + PBYTES + (wid + 4 * j) * 1024), 16,
+                                                         wvoff2[j], soff, 0, 0);
+            return;
+        }
         const int soff = (tap_of(j_) * C + cc * 64) * 2;
 #pragma unroll
         for (int j = 0; j < WPW; ++j)
@@ -264,6 +284,14 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         const int r = (a.S == 3) ? ((tap * 11) >> 5) : tap, s = tap - r * a.S;
         const int toff = a.mode == 0 ? ((r * W + s) * C + cc * 64) * 2
                                      : (cc * 64 - ((r >> p.s_shift) * W + (s >> p.s_shift)) * C) * 2;
+        if (j_ >= ntap) {              // (uniform) the second source: same pixels as the centre tap, its own tensor
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned off = ((vmask[j] >> tap) & 1) ? (unsigned)(pixoff[j] + toff) : kDmaOob;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc2, (lds_void_t *)(smem + sbase + (wid + 4 * j) * 1024), 16, off, 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned off = ((vmask[j] >> tap) & 1) ? (unsigned)(pixoff[j] + toff) : kDmaOob;
@@ -643,6 +671,8 @@ void fill(const combat_conv_args *a, GatherParams &p) {
     p.flavour = epi_flavour_of(*a);
     p.block_base = 0;
     p.w_prefetch = (long)a->C * p.ntaps >= 1024 && !getenv("COMBAT_NO_WPREFETCH");   // >= 16 lines per weight row
+    p.cpt2 = a->src2 ? p.cpt : 0;      // (the second source has the first one's shape: conv_gather_dma_src2_ok)
+    p.w2_bytes = a->src2 ? (unsigned)((long)a->rows_pad2 * a->kpad2 * 2) : 0u;
 #ifdef COMBAT_STAMPS
     p.stamps = g_stamps_gather_host;
 #else
@@ -732,7 +762,15 @@ int conv_c8_launch(const combat_conv_args *a, hipStream_t st) {
 bool conv_gather_dma_parity_split(const combat_conv_args *a);
 
 // 0 / BN (64 or 32) this kernel would use for these args
+// the optional second reduction source (combat_conv_args.src2): what the kernel's extra steps assume
+bool conv_gather_dma_src2_ok(const combat_conv_args *a) {
+    if (!a->src2) return true;
+    return a->wpack2 && a->mode == 1 && a->R == 3 && a->S == 3 && a->stride == 2 && a->pad == 1 && a->kpad2 >= a->C &&
+           (a->kpad2 & 63) == 0 && a->rows_pad2 >= a->K && (long)a->rows_pad2 * a->kpad2 * 2 < 0x40000000L;
+}
+
 int conv_gather_dma_bn(const combat_conv_args *a) {
+    if (!conv_gather_dma_src2_ok(a)) return 0;
     if (a->pro_scale || a->pro_act || a->tanh_out) return 0;
     if (a->mask_x && a->act_dst) return 0;
     if (a->R != a->S || (a->R != 1 && a->R != 3) || (a->stride != 1 && a->stride != 2)) return 0;

@@ -310,6 +310,11 @@ int launch(const ConvParams &p, hipStream_t st) {
 }
 
 int pick_tile(const combat_conv_args *a) {
+    if (a->src2) {   // a second reduction source: the gathered-DMA kernel or nothing
+        if (a->tile && a->tile != COMBAT_TILE_G128x64 && a->tile != COMBAT_TILE_G128x32) return 0;
+        const int bn = conv_gather_dma_bn(a);
+        return !bn ? 0 : (bn == 64 ? COMBAT_TILE_G128x64 : COMBAT_TILE_G128x32);
+    }
     if (a->tile == 0 && a->workspace && conv_gather_dma_workspace(a) > 0 &&
         a->workspace_bytes >= conv_gather_dma_workspace(a))   // skinny layer: split reduction beats any single-workgroup tile
         return conv_gather_dma_bn(a) == 64 ? COMBAT_TILE_G128x64 : COMBAT_TILE_G128x32;

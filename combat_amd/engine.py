@@ -40,6 +40,7 @@ class Plan:
     """An ordered list of C-ABI calls with pre-marshalled arguments (stream appended at run)."""
 
     serial = False   # True: auxiliary-stream calls run in line (kernel-level measurements: one kernel at a time)
+    serial_shortcuts = False   # True: shortcut input gradients as launches of their own (per-launch profiling, A/B)
     default_aux_queues = 1   # auxiliary queues a new plan deals its aux calls to (see aux_queues below)
     flush_at_marks = False   # data parallel: deferred weight-gradient reductions are issued at every all-reduce mark
     #                          (the gradients above a mark must be final there); otherwise all of them at the end of
@@ -471,6 +472,18 @@ def _tile_preference(a) -> None:
         a.tile = TILE_D128x64
 
 
+FUSE_SHORTCUT = os.environ.get("COMBAT_NO_FUSED_SHORTCUT", "0") != "1"
+
+
+def fuse_shortcut(dy, dx, pc: PackedConv, dy_sc, pc_sc: PackedConv):
+    """The `shortcut=` argument of the block's first convolution's input gradient (dy -> dx through `pc`, 3x3 / stride
+    2) if the 1x1 / stride-2 shortcut's input gradient (dy_sc through `pc_sc`) can ride along as a second reduction
+    source (combat_conv_args.src2: one launch, no intermediate tensor), else None (two launches)."""
+    if FUSE_SHORTCUT and not Plan.serial_shortcuts and ops.shortcut_fusable(dy, dx, pc, pc_sc) and tuple(dy_sc.shape) == tuple(dy.shape):
+        return (dy_sc, pc_sc)
+    return None
+
+
 def rec_conv(plan: Plan, what: str, src, dst, pc: PackedConv, mode: int, **kw):
     a = ops.conv_args(src, dst, pc, mode, workspace=plan.workspace(src.device), **kw)
     _tile_preference(a)
@@ -693,7 +706,7 @@ class NetEngine:
                  _p(q["nbt"]), self._scratch.data_ptr(), self._scratch.numel() * 4, act_dst.data_ptr())
 
     def _dgrad_norm(self, plan: Plan, slot: Slot, key: str, dy, dz, pc: PackedConv, x_pre, st: NormState, *,
-                    group_stride: int, slope: float, gamma=None, dgamma=None, dbeta=None, add_pre=None):
+                    group_stride: int, slope: float, gamma=None, dgamma=None, dbeta=None, add_pre=None, shortcut=None):
         """dgrad whose epilogue applies the activation mask of the conv input (recomputed from the
         saved pre-norm tensor x_pre) and emits the two norm-backward reductions.  The caller's
         `_bwd_apply` turns them into coefficients and applies those in one launch."""
@@ -701,7 +714,8 @@ class NetEngine:
         pq, m = p * q, n * p * q
         groups = st.groups
         mask = Affine(st.scale, st.shift, group_stride, True, slope)
-        a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask, workspace=plan.workspace(dy.device))
+        a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask, workspace=plan.workspace(dy.device),
+                          shortcut=shortcut)
         _tile_preference(a)
         a.stats_kind = 2 | (BATCH_STATS_ROWS if groups == 1 else 0)
         a.xh_mean, a.xh_rstd = st.mean.data_ptr(), st.rstd.data_ptr()
@@ -981,16 +995,18 @@ class PreActEngine(NetEngine):
                              dbeta=fp.grad_phys(pre + "bn2.bias"))
             dy1 = slot.buf("g.b%d.dy1" % b, y1.shape)
             self._bwd_apply(P, slot, "g." + blk.bn2.prefix, dz2, y1, dy1, st2)
-            tsc = None
+            tsc, fused = None, None
+            dz1 = slot.buf("g.b%d.dz1" % b, xin.shape)
             if blk.sc is not None:
                 rec_wgrad(P, "b%d.sc.wgrad" % b, a0, d_out, blk.sc, fp.grad_phys(pre + "shortcut.0.weight"))
-                tsc = slot.buf("g.b%d.tsc" % b, xin.shape)
-                rec_conv(P, "b%d.sc.dgrad" % b, d_out, tsc, blk.sc, 1)
+                fused = fuse_shortcut(dy1, dz1, blk.conv1, d_out, blk.sc)    # the shortcut's input gradient rides along below
+                if fused is None:
+                    tsc = slot.buf("g.b%d.tsc" % b, xin.shape)
+                    rec_conv(P, "b%d.sc.dgrad" % b, d_out, tsc, blk.sc, 1)
             rec_wgrad(P, "b%d.c1.wgrad" % b, a0, dy1, blk.conv1, fp.grad_phys(pre + "conv1.weight"))
-            dz1 = slot.buf("g.b%d.dz1" % b, xin.shape)
             self._dgrad_norm(P, slot, "g." + blk.bn1.prefix, dy1, dz1, blk.conv1, xin, st1, group_stride=0,
                              slope=0.0, gamma=blk.bn1.gamma, dgamma=fp.grad_phys(pre + "bn1.weight"),
-                             dbeta=fp.grad_phys(pre + "bn1.bias"), add_pre=tsc)
+                             dbeta=fp.grad_phys(pre + "bn1.bias"), add_pre=tsc, shortcut=fused)
             dxin = slot.buf("g.b%d.dx" % b, xin.shape)
             self._bwd_apply(P, slot, "g." + blk.bn1.prefix, dz1, xin, dxin, st1,
                             add=None if blk.sc is not None else d_out)
@@ -1026,12 +1042,14 @@ class PreActEngine(NetEngine):
             dy1 = slot.buf("g.b%d.dy1" % b, a1.shape)
             rec_conv(P, "b%d.c2.dgrad" % b, d_out, dy1, blk.conv2, 1, mask_x=a1, mask=blk.bn2.eval_affine(),
                      mask_mul_scale=True, mask_activated=True)
-            tsc = None
-            if blk.sc is not None:
-                tsc = slot.buf("g.b%d.tsc" % b, xact.shape)
-                rec_conv(P, "b%d.sc.dgrad" % b, d_out, tsc, blk.sc, 1)
+            tsc, fused = None, None
             dxin = slot.buf("g.b%d.dx" % b, xact.shape)
-            rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=tsc, mask_x=xact,
+            if blk.sc is not None:
+                fused = fuse_shortcut(dy1, dxin, blk.conv1, d_out, blk.sc)
+                if fused is None:
+                    tsc = slot.buf("g.b%d.tsc" % b, xact.shape)
+                    rec_conv(P, "b%d.sc.dgrad" % b, d_out, tsc, blk.sc, 1)
+            rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, shortcut=fused, add_pre=tsc, mask_x=xact,
                      mask=blk.bn1.eval_affine(), mask_mul_scale=True, mask_activated=True,
                      add_post=None if blk.sc is not None else d_out)
             d_out = dxin
@@ -1197,12 +1215,10 @@ class ResNetEngine(PreActEngine):
             cur_in = self._block_in(slot, b)
             y1, a1, y2 = slot.bufs["b%d.y1" % b], slot.bufs["b%d.a1" % b], slot.bufs["b%d.y2" % b]
             dy2 = bn_bwd(blk.bn2, "g." + blk.bn2.prefix, d_out, y2, "b%d.dy2" % b)
-            tsc = None
+            tsc, dys = None, None
             if blk.sc is not None:
                 dys = bn_bwd(blk.bns, "g." + blk.bns.prefix, d_out, slot.bufs["b%d.ys" % b], "b%d.dys" % b)
                 rec_wgrad(P, "b%d.sc.wgrad" % b, cur_in, dys, blk.sc, fp.grad_phys(pre + "shortcut.0.weight"))
-                tsc = G("b%d.tsc" % b, cur_in)
-                rec_conv(P, "b%d.sc.dgrad" % b, dys, tsc, blk.sc, 1)
             rec_wgrad(P, "b%d.c2.wgrad" % b, a1, dy2, blk.conv2, fp.grad_phys(pre + "conv2.weight"))
             st1 = slot.norm[blk.bn1.prefix]
             dz1 = G("b%d.dz1" % b, y1)
@@ -1212,10 +1228,17 @@ class ResNetEngine(PreActEngine):
             dy1 = G("b%d.dy1" % b, y1)
             self._bwd_apply(P, slot, "g." + blk.bn1.prefix, dz1, y1, dy1, st1)
             rec_wgrad(P, "b%d.c1.wgrad" % b, cur_in, dy1, blk.conv1, fp.grad_phys(pre + "conv1.weight"))
-            other = tsc if blk.sc is not None else d_out        # the shortcut's share of the block-input gradient
+            dxin = G("b%d.dx" % b, cur_in) if b > 0 else None
+            fused = None
+            if blk.sc is not None:       # the shortcut's share of the block-input gradient: along with conv1's, or a launch
+                fused = fuse_shortcut(dy1, dxin, blk.conv1, dys, blk.sc) if b > 0 else None
+                if fused is None:
+                    tsc = G("b%d.tsc" % b, cur_in)
+                    rec_conv(P, "b%d.sc.dgrad" % b, dys, tsc, blk.sc, 1)
+            other = (None if fused is not None else tsc) if blk.sc is not None else d_out
             if b > 0:   # through the previous block's final ReLU
-                dxin = G("b%d.dx" % b, cur_in)
-                rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=other, mask_x=cur_in, mask_activated=True)
+                rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, shortcut=fused, add_pre=other, mask_x=cur_in,
+                         mask_activated=True)
                 d_out = dxin
                 if b in (6, 4, 2):
                     P.mark(fp.offsets[pre + "conv1.weight"][0])
@@ -1247,13 +1270,17 @@ class ResNetEngine(PreActEngine):
             dy1 = slot.buf("g.b%d.dy1" % b, a1.shape)
             rec_conv(P, "b%d.c2.dgrad" % b, d_out, dy1, blk.conv2e, 1, mask_x=a1, mask=blk.bn1.eval_affine(),
                      mask_mul_scale=True, mask_activated=True)
-            other = d_out
-            if blk.sc is not None:
-                other = slot.buf("g.b%d.tsc" % b, cur_in.shape)
-                rec_conv(P, "b%d.sc.dgrad" % b, d_out, other, blk.sce, 1)
+            other, fused = d_out, None
             dxin = slot.buf("g.b%d.dx" % b, cur_in.shape)
+            if blk.sc is not None:
+                fused = fuse_shortcut(dy1, dxin, blk.conv1, d_out, blk.sce) if b > 0 else None
+                other = None
+                if fused is None:
+                    other = slot.buf("g.b%d.tsc" % b, cur_in.shape)
+                    rec_conv(P, "b%d.sc.dgrad" % b, d_out, other, blk.sce, 1)
             if b > 0:
-                rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=other, mask_x=cur_in, mask_activated=True)
+                rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, shortcut=fused, add_pre=other, mask_x=cur_in,
+                         mask_activated=True)
             else:
                 rec_conv(P, "b%d.c1.dgrad" % b, dy1, dxin, blk.conv1, 1, add_pre=other, mask_x=cur_in,
                          mask=self.bn0.eval_affine(), mask_mul_scale=True, mask_activated=True)

@@ -110,7 +110,7 @@ class PackedConv:
 def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = None, bias=None, add_pre=None,
               mask_x=None, mask: Optional[Affine] = None, mask_mul_scale=False, add_post=None, tanh_out=False,
               stats_kind=0, stats=None, xh_mean=None, xh_rstd=None, tile=0, act_dst=None,
-              act: Optional[Affine] = None, mask_activated=False, workspace=None) -> ConvArgs:
+              act: Optional[Affine] = None, mask_activated=False, workspace=None, shortcut=None) -> ConvArgs:
     """act_dst / act: second output bf16(lrelu(y * act.scale + act.shift)) of the stored value y (the
     next layer's eval-mode BatchNorm + ReLU); dst may then be None.  mask_activated: mask_x is such an
     activation (kept-test mask_x > 0)."""
@@ -140,14 +140,27 @@ def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = No
     a.stats_kind, a.stats = stats_kind, _p(stats)
     a.xh_mean, a.xh_rstd = _p(xh_mean), _p(xh_rstd)
     a.tile = tile
+    if shortcut is not None:    # (dY of the block's 1x1 / stride-2 shortcut, its PackedConv): second reduction source
+        src2, pc2 = shortcut
+        assert mode == 1 and tuple(src2.shape) == tuple(src.shape)
+        a.src2, a.wpack2, a.kpad2, a.rows_pad2 = src2.data_ptr(), pc2.wd.data_ptr(), pc2.kpad_d, pc2.rows_d
     if workspace is not None:   # scratch for a split reduction (skinny layers); set before any layout query
         need = int(lib.combat_conv_workspace_bytes(ctypes.byref(a)))
         if 0 < need <= workspace.numel() * workspace.element_size():
             a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     # the struct holds raw pointers: keep every tensor alive as long as the struct is
     a._keepalive = (src, dst, pc, pro, bias, add_pre, mask_x, mask, add_post, stats, xh_mean, xh_rstd, act_dst, act,
-                    workspace)
+                    workspace, shortcut)
     return a
+
+
+def shortcut_fusable(dy, dx, pc: PackedConv, pc_sc: PackedConv) -> bool:
+    """Can the input gradient of `pc` (3x3 / stride 2) take the block's 1x1 / stride-2 shortcut `pc_sc` along as a second
+    reduction source (combat_conv_args.src2)?  True when a kernel takes such a launch."""
+    if pc_sc.R != 1 or pc_sc.stride != 2 or pc_sc.wd is None:
+        return False
+    a = conv_args(dy, dx, pc, 1, shortcut=(dy, pc_sc))
+    return lib.combat_conv_pick_tile(ctypes.byref(a)) > 0
 
 
 def conv_tile_granule(a: ConvArgs):

@@ -114,6 +114,14 @@ typedef struct combat_conv_args {
     void *workspace;
     int64_t workspace_bytes;
     int32_t tile;                /* 0 = auto; else a COMBAT_TILE_* value */
+    /* second reduction source (may be NULL; mode 1 with R = S = 3, stride 2, pad 1, on the gathered-DMA kernel only):
+       dst also receives the input gradient of a 1x1 / stride-2 / pad-0 convolution over src2 -- a tensor of src's
+       shape -- with operand wpack2 [rows_pad2][kpad2] (rows = K, k = channel of src2): a residual block's shortcut
+       (preact_resnet.py:27-36, resnet.py:24-31).  Its gradient lands exactly on the pixels of the 3x3 convolution's
+       centre tap, so it rides along as C / 64 more reduction steps: one launch instead of two and no intermediate
+       tensor; the epilogue (mask, statistics, residuals) then sees the sum, as it did through add_pre. */
+    const void *src2, *wpack2;
+    int32_t kpad2, rows_pad2;
 } combat_conv_args;
 
 #define COMBAT_STATS_PER_WORKGROUP 4

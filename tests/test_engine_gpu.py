@@ -646,7 +646,9 @@ def test_plan_replay_in_c_equals_python_replay(mods):
     for serial in (False, True):
         py1, py2, c1 = run(False, serial), run(False, serial), run(True, serial)
         noise = dist(py1, py2)
-        assert dist(py1, c1) <= max(3 * noise, 1e-7) and dist(py1, c1) < 1e-5, (serial, noise, dist(py1, c1))
+        # (two samples underestimate the noise: a single tensor whose fp32-atomic reduction happened to run in another
+        # order moves by ~5e-7 -- seen between two replays of EITHER kind; real ordering bugs move results by >= 1e-3)
+        assert dist(py1, c1) <= max(3 * noise, 2e-6) and dist(py1, c1) < 1e-5, (serial, noise, dist(py1, c1))
         for k in ("clean_correct", "bd_correct", "train_correct", "clean_model_correct"):
             assert py1[1][k] == c1[1][k]
         for k in ("loss_c_sum", "loss_ce_sum", "clean_model_loss_sum", "loss_l2_sum"):

@@ -599,6 +599,58 @@ def test_conv_stride2_dgrad_parity_classes(ops, n, hw, c, k, r):
     assert rel_l2(stats.sum(0).cpu()[1], (got * got).sum((0, 2, 3))) < 1e-4
 
 
+@pytest.mark.parametrize("n,hw,c,k", [(8, 32, 64, 128), (4, 16, 128, 256), (16, 8, 256, 512), (3, 32, 64, 128), (5, 10, 64, 64)])
+def test_conv_stride2_dgrad_with_shortcut_as_second_source(ops, n, hw, c, k):
+    """combat_conv_args.src2: the input gradient of a residual block's 1x1 / stride-2 shortcut rides along in the 3x3 /
+    stride-2 input-gradient launch as extra reduction steps on the centre tap's pixels (parity-class-major order: the
+    (even, even) class only; linear order -- class size not a multiple of the tile, odd maps -- by the tap's validity
+    bits; skinny layers with a split reduction).  Against the two-launch form (shortcut gradient through add_pre: what
+    the plans did before) with the same mask + statistics epilogue, and against torch."""
+    from combat_amd._lib import lib
+    import ctypes
+    w3, pc3 = make_conv(ops, k, c, 3, 2, 1, 501)
+    w1, pc1 = make_conv(ops, k, c, 1, 2, 0, 502)
+    p = (hw + 1) // 2
+    dy3, dy1 = torch.randn(n, k, p, p, generator=g(503)), torch.randn(n, k, p, p, generator=g(504))
+    xpre = torch.randn(n, c, hw, hw, generator=g(505))
+    sc, sh = torch.rand(c, generator=g(506)) - 0.3, torch.randn(c, generator=g(507)) * 0.3
+    mean, rstd = dev(torch.randn(c, generator=g(508)) * 0.1), dev(torch.rand(c, generator=g(509)) + 0.5)
+    mask = ops.Affine(dev(sc), dev(sh), 0, True, 0.0)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+
+    def run(fused):
+        dx = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+        tsc = None
+        if not fused:
+            tsc = torch.empty(n, hw, hw, c, dtype=bf16, device="cuda")
+            ops.conv_launch(ops.conv_args(nhwc(dy1), tsc, pc1, 1))
+        a = ops.conv_args(nhwc(dy3), dx, pc3, 1, add_pre=tsc, mask_x=nhwc(xpre), mask=mask, stats_kind=2, xh_mean=mean,
+                          xh_rstd=rstd, workspace=ws, shortcut=(nhwc(dy1), pc1) if fused else None)
+        assert lib.combat_conv_pick_tile(ctypes.byref(a)) in (12, 13)
+        rows, _ = ops.conv_stats_layout(a)
+        stats = torch.zeros(rows, 2, c, device="cuda")
+        a.stats = stats.data_ptr()
+        ops.conv_launch(a)
+        torch.cuda.synchronize()
+        return nchw(dx), stats.sum(0).cpu()
+
+    if hw % 2:      # (odd maps: the 1x1's output is one pixel larger than the 3x3's would need -- not a shortcut geometry)
+        pytest.skip("odd map")
+    (dx_f, st_f), (dx_2, st_2) = run(True), run(False)
+    gin = (torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w3), rb(dy3), stride=2, padding=1) +
+           torch.nn.grad.conv2d_input((n, c, hw, hw), rb(w1), rb(dy1), stride=2, padding=0))
+    keep = (rb(xpre) * sc[None, :, None, None] + sh[None, :, None, None]) > 0
+    ref = torch.where(keep, gin, torch.zeros_like(gin))
+    assert rel_l2(dx_f, ref) < 4e-3
+    assert rel_l2(dx_f, dx_2) < 3e-3           # (the two-launch form rounds the shortcut's gradient to bf16 in between)
+    assert rel_l2(st_f, st_2) < 3e-3
+    assert ops.shortcut_fusable(nhwc(dy3), torch.empty(n, hw, hw, c, dtype=bf16, device="cuda"), pc3, pc1)
+    # not a shortcut geometry: stride-1 3x3, or a 3x3 "shortcut"
+    w31, pc31 = make_conv(ops, k, c, 3, 1, 1, 510)
+    assert not ops.shortcut_fusable(nhwc(torch.randn(n, k, hw, hw)), torch.empty(n, hw, hw, c, dtype=bf16, device="cuda"), pc31, pc1)
+    assert not ops.shortcut_fusable(nhwc(dy3), torch.empty(n, hw, hw, c, dtype=bf16, device="cuda"), pc3, pc3)
+
+
 @pytest.mark.parametrize("n,hw,c,k,r,stride,mode", [(16, 2, 512, 512, 3, 1, 0), (16, 2, 512, 512, 3, 1, 1), (9, 4, 256, 256, 3, 1, 0),
                                                    (32, 8, 256, 512, 3, 2, 0), (10, 4, 512, 128, 1, 1, 0)])
 def test_conv_split_reduction(ops, n, hw, c, k, r, stride, mode):
