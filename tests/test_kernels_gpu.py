@@ -1120,8 +1120,8 @@ def test_bn_eval_fold(ops):
 # ---------------------------------------------------------------- UNet glue
 
 
-def test_unet_up_forward_backward(ops):
-    n, hw, c = 3, 8, 64
+@pytest.mark.parametrize("n,hw,c", [(3, 8, 64), (2, 16, 128), (2, 6, 64), (2, 4, 512)])
+def test_unet_up_forward_backward(ops, n, hw, c):
     y = torch.randn(n, c, hw, hw, generator=g(80))
     s = torch.randn(n, c, hw, hw, generator=g(81))
     sy, ty = torch.rand(n, c, generator=g(82)) + 0.5, torch.randn(n, c, generator=g(83)) * 0.2
