@@ -60,7 +60,10 @@ __device__ __forceinline__ void wait_vm_lgkm0_bar() {
 // FINISH = false: the convolution (whole, or one slab of a split reduction).  FINISH = true: the second
 // launch of a split reduction: sum the slabs into the accumulators and run the fused epilogue.
 // NS = stages of the LDS ring (steps are issued NS - 1 ahead); 3 is what launches use (see launch()).
-template <int BN, bool FINISH, int NS>
+// SRC2: the launch has a second reduction source (combat_conv_args.src2); a separate instantiation, because its two
+// extra buffer resources and operand offsets push the kernel over its 104 scalar registers (spills inside the main
+// loop: 30 -> 45 us on a stride-2 input gradient when every launch carried them).
+template <int BN, bool FINISH, int NS, bool SRC2 = false>
 __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     constexpr int BM = 128;
     using T = TileCfg<BM, BN, 4>;           // four waves along the pixels: a wave owns 32 pixels x all BN channels
@@ -119,9 +122,7 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     // second source (a residual block's 1x1 / stride-2 shortcut, input gradient): its pixels are those of the 3x3's
     // centre tap, so its chunks are cpt2 more reduction steps "tap index ntap" -- in parity-class-major order only the
     // (even, even) class reaches them, otherwise the centre tap's validity bit decides per pixel
-    const bool has2 = p.cpt2 > 0 && (!p.psplit || pcls == 0);
-    const __amdgpu_buffer_rsrc_t srsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src2), 0, has2 ? p.src_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack2), 0, has2 ? p.w2_bytes : 0u, 0x00020000);
+    const bool has2 = SRC2 && p.cpt2 > 0 && (!p.psplit || pcls == 0);
     const int nsteps_all = ntap * p.cpt + (has2 ? p.cpt2 : 0);
     int g_lo = 0, nsteps = nsteps_all;
     if (p.splits > 1) {
@@ -140,7 +141,7 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         }
     };
     auto tap_of = [&](int j_) __attribute__((always_inline)) {
-        if (j_ >= ntap) return 4;      // the second source's steps: addressed as the centre tap
+        if (SRC2 && j_ >= ntap) return 4;      // the second source's steps: addressed as the centre tap
         return p.psplit ? (taplist >> (4 * j_)) & 15 : j_;
     };
     unsigned wvoff[WPW], wvoff2[WPW];
@@ -148,11 +149,13 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
     for (int j = 0; j < WPW; ++j) {
         const int n = (wid + 4 * j) * 8 + (lane >> 3), slot = lane & 7;
         wvoff[j] = (unsigned)(((n0 + n) * a.kpad + ((slot - (n & 6)) & 7) * 8) * 2);
-        wvoff2[j] = (unsigned)(((n0 + n) * a.kpad2 + ((slot - (n & 6)) & 7) * 8) * 2);
+        wvoff2[j] = SRC2 ? (unsigned)(((n0 + n) * a.kpad2 + ((slot - (n & 6)) & 7) * 8) * 2) : 0u;
     }
     auto issue_w = [&](int j_, int cc, auto stage_tag) __attribute__((always_inline)) {
         constexpr int sbase = decltype(stage_tag)::value * SBYTES;
-        if (j_ >= ntap) {              // (uniform) the shortcut's operand: one tap, k = channel
+        if (SRC2 && j_ >= ntap) {      // (uniform) the shortcut's operand: one tap, k = channel.  (Its resource is built
+            // here, per step: scalar registers are what this kernel is short of.)
+            const __amdgpu_buffer_rsrc_t wrsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack2), 0, p.w2_bytes, 0x00020000);
             const int soff = cc * 64 * 2;
 #pragma unroll
             for (int j = 0; j < WPW; ++j)
@@ -284,7 +287,8 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
         const int r = (a.S == 3) ? ((tap * 11) >> 5) : tap, s = tap - r * a.S;
         const int toff = a.mode == 0 ? ((r * W + s) * C + cc * 64) * 2
                                      : (cc * 64 - ((r >> p.s_shift) * W + (s >> p.s_shift)) * C) * 2;
-        if (j_ >= ntap) {              // (uniform) the second source: same pixels as the centre tap, its own tensor
+        if (SRC2 && j_ >= ntap) {      // (uniform) the second source: same pixels as the centre tap, its own tensor
+            const __amdgpu_buffer_rsrc_t srsrc2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src2), 0, p.src_bytes, 0x00020000);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned off = ((vmask[j] >> tap) & 1) ? (unsigned)(pixoff[j] + toff) : kDmaOob;
@@ -494,8 +498,10 @@ __device__ __forceinline__ void conv_gather_dma_body(const GatherParams &p) {
 // lambdas -- so the kernels below call it in the device pass only; the host pass needs just their stubs)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define COMBAT_GATHER_BODY(BN, NS, P) conv_gather_dma_body<BN, false, NS>(P)
+#define COMBAT_GATHER_BODY2(BN, NS, P) conv_gather_dma_body<BN, false, NS, true>(P)
 #else
 #define COMBAT_GATHER_BODY(BN, NS, P) ((void)(P))
+#define COMBAT_GATHER_BODY2(BN, NS, P) ((void)(P))
 #endif
 
 struct GatherPair {
@@ -512,6 +518,10 @@ struct GatherPair {
 template <int BN, int NS>
 __global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_kernel(const GatherParams p) {
     COMBAT_GATHER_BODY(BN, NS, p);
+}
+template <int BN, int NS>     // ... with a second reduction source
+__global__ __launch_bounds__(256, NS > 3 ? 1 : 2) void conv_gather_dma_src2_kernel(const GatherParams p) {
+    COMBAT_GATHER_BODY2(BN, NS, p);
 }
 
 // Workgroups [0, n0) run problem 0, the rest problem 1.  Two independent
@@ -690,11 +700,12 @@ int launch(const combat_conv_args *a, hipStream_t st) {
     // (A six-stage ring for launches of at most one workgroup per CU -- ring depth is a template parameter --
     // changed nothing on the kernel alone and cost the step 1.5 %: a workgroup holding 144 KB of LDS keeps the
     // other streams' workgroups off its CU.  What bounds a lone workgroup is in-order issue, not DMA latency.)
-    auto kern = conv_gather_dma_kernel<BN, 3>;
+    auto kern = a->src2 ? conv_gather_dma_src2_kernel<BN, 3> : conv_gather_dma_kernel<BN, 3>;
     auto fin = conv_gather_finish_kernel<BN>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gather_dma_kernel<BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gather_dma_src2_kernel<BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void *>(fin), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
             return COMBAT_ELAUNCH;
         attr_set = true;

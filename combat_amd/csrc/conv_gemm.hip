@@ -412,6 +412,7 @@ static int validate_conv_args(const combat_conv_args *a) {
     if ((a->pro_scale == nullptr) != (a->pro_shift == nullptr)) return COMBAT_EINVAL;
     if (a->mask_scale && !a->mask_shift) return COMBAT_EINVAL;
     if (a->mask_mul_scale && !a->mask_scale) return COMBAT_EINVAL;
+    if ((a->src2 == nullptr) != (a->wpack2 == nullptr)) return COMBAT_EINVAL;
     const int skind = a->stats_kind & 3;
     if (a->stats_kind < 0 || (a->stats_kind & ~(3 | COMBAT_STATS_PER_WORKGROUP)) || skind == 3 || (!skind && a->stats_kind) ||
         (skind && !a->stats))
@@ -430,7 +431,7 @@ extern "C" int combat_conv_gemm_pair(const combat_conv_args *a, const combat_con
     COMBAT_PLAN_HOOK(combat_conv_gemm_pair, a, b);
     if (validate_conv_args(a) != COMBAT_OK || validate_conv_args(b) != COMBAT_OK) return COMBAT_EINVAL;
     const int ta = pick_tile(a), tb = pick_tile(b);
-    const bool gather = (ta == COMBAT_TILE_G128x64 || ta == COMBAT_TILE_G128x32) && ta == tb;
+    const bool gather = (ta == COMBAT_TILE_G128x64 || ta == COMBAT_TILE_G128x32) && ta == tb && !a->src2 && !b->src2;
     if (gather) {
         const int rc = conv_gather_dma_pair_launch(a, b, as_stream(stream));
         if (rc != 1) return rc;
