@@ -33,5 +33,6 @@ def run(groups, pxg, c, gran=32, reps=50):
         e1.record(); torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / reps * 1e3)
     print('groups %4d pxg %6d C %3d rows/group %4d: act_fused %.1f us  bwd_fused %.1f us  (affine_act alone %.1f us)  tensor %.1f MB' % (groups, pxg, c, rpg, out[0], out[1], out[2], rows * c * 2 / 1e6), flush=True)
-run(1, 131072, 64); run(1, 32768, 128); run(1, 8192, 256); run(1, 2048, 512)
+run(1, 131072, 64, 512); run(1, 32768, 128, 128); run(1, 8192, 256, 128); run(1, 2048, 512, 128)   # BatchNorm: one row per workgroup
+run(1, 131072, 64); run(1, 32768, 128)     # ... per wave (norm_stage1 first)
 run(128, 256, 64); run(128, 64, 128); run(128, 256, 128)
