@@ -126,6 +126,39 @@ def test_tile_choice_and_stats_layout_are_host_queries(L):
     assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) in (L.TILE_64x64, L.TILE_64x128)      # with a prologue: register-staged gather
 
 
+def test_eight_channel_and_shortcut_launch_forms_are_host_queries(L):
+    """COMBAT_TILE_K8 and the second reduction source (combat_conv_args.src2) are decided on the host: which launches take
+    them, and that a malformed one is rejected before any HIP call."""
+    a = L.ConvArgs()
+    a.src = a.wpack = a.dst = 4096
+    a.N, a.H, a.W, a.C, a.P, a.Q, a.K = 128, 32, 32, 64, 32, 32, 8              # generator output layer / stem input gradient
+    a.R = a.S = 3
+    a.stride, a.pad, a.kpad, a.rows_pad = 1, 1, 576, 16
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_K8
+    a.mode = 1
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) == L.TILE_K8
+    a.add_post = 4096                                                            # a residual operand: the general kernels
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) != L.TILE_K8
+    a.add_post, a.H, a.W, a.P, a.Q = None, 12, 12, 12, 12                        # not whole 16 x 8 tiles
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(a)) != L.TILE_K8
+    # a block's stride-2 input gradient with its shortcut as second source: src = dY [N,16,16,128] -> dst = dX [N,32,32,64]
+    b = L.ConvArgs()
+    b.src = b.wpack = b.dst = 4096
+    b.N, b.H, b.W, b.C, b.P, b.Q, b.K = 128, 16, 16, 128, 32, 32, 64
+    b.R = b.S = 3
+    b.stride, b.pad, b.kpad, b.rows_pad, b.mode = 2, 1, 1152, 64, 1
+    plain = L.lib.combat_conv_pick_tile(ctypes.byref(b))
+    assert plain in (L.TILE_G128x64, L.TILE_G128x32)
+    b.src2, b.wpack2, b.kpad2, b.rows_pad2 = 4096, 4096, 128, 64
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(b)) == plain
+    b.mode = 0                                                                   # forward launches have no such form
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(b)) == 0
+    b.mode, b.kpad2 = 1, 64                                                      # operand shorter than the reduction
+    assert L.lib.combat_conv_pick_tile(ctypes.byref(b)) == 0
+    b.kpad2, b.wpack2 = 128, None                                                # a source without its operand
+    assert L.lib.combat_conv_gemm(ctypes.byref(b), None) == -1
+
+
 def test_modules_have_no_cpu_fallback():
     from combat_amd import nets
     from combat_amd._lib import CombatHipError
