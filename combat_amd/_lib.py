@@ -118,6 +118,7 @@ SIGNATURES = {
     "combat_nhwc_to_nchw_f32": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_nchw_to_nhwc_bf16": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "combat_memset_zero": (C.c_int, [c_vp, c_i64, c_vp]),
+    "combat_copy3": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
     "combat_relu_mask": (C.c_int, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     "combat_colsum": (C.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "combat_log_terms": (C.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),

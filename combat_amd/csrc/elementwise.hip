@@ -550,6 +550,74 @@ extern "C" int combat_memset_zero(void *ptr, int64_t bytes, void *stream) {
     return hipMemsetAsync(ptr, 0, (size_t)bytes, as_stream(stream)) == hipSuccess ? COMBAT_OK : COMBAT_ELAUNCH;
 }
 
+// ------------------------------------------------------------------ the step's small copies, one launch
+// Up to three byte copies in ONE kernel launch (grid.y = copy): the step table (from PINNED host memory, read through its
+// device mapping), the batch, a re-packed bias.  As three asynchronous copies they cost the critical queue 18 us of
+// copy kernels plus 27 us of idle time in front of them at every step boundary (tools/timeline.py).
+struct Copy3Args {
+    void *dst[3];
+    const void *src[3];
+    long bytes[3];
+};
+__global__ __launch_bounds__(256) void copy3_kernel(const Copy3Args a) {
+    const int k = blockIdx.y;
+    const long n = a.bytes[k];
+    unsigned char *__restrict__ d = reinterpret_cast<unsigned char *>(a.dst[k]);
+    const unsigned char *__restrict__ s = reinterpret_cast<const unsigned char *>(a.src[k]);
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
+    if ((((unsigned long)d | (unsigned long)s) & 15) == 0) {
+        const long n16 = n >> 4;
+        for (long i = t; i < n16; i += step) reinterpret_cast<uint4 *>(d)[i] = reinterpret_cast<const uint4 *>(s)[i];
+        for (long i = (n16 << 4) + t; i < n; i += step) d[i] = s[i];
+    } else {
+        for (long i = t; i < n; i += step) d[i] = s[i];
+    }
+}
+
+extern "C" int combat_copy3(void *dst0, const void *src0, int64_t bytes0, void *dst1, const void *src1, int64_t bytes1,
+                            void *dst2, const void *src2, int64_t bytes2, void *stream) {
+    COMBAT_PLAN_HOOK(combat_copy3, dst0, src0, bytes0, dst1, src1, bytes1, dst2, src2, bytes2);
+    Copy3Args a;
+    void *dst[3] = {dst0, dst1, dst2};
+    const void *src[3] = {src0, src1, src2};
+    const int64_t bytes[3] = {bytes0, bytes1, bytes2};
+    hipStream_t st = as_stream(stream);
+    int n = 0;
+    long most = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (bytes[k] < 0 || (bytes[k] > 0 && (!dst[k] || !src[k]))) return COMBAT_EINVAL;
+        if (bytes[k] == 0) continue;
+        // a host source must be reachable from the device (pinned memory is mapped); anything else: an ordinary copy
+        hipPointerAttribute_t at;
+        const void *dev_src = src[k];
+        if (hipPointerGetAttributes(&at, dst[k]) != hipSuccess || (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) ||
+            hipPointerGetAttributes(&at, src[k]) != hipSuccess) {      // (a destination the kernel may not write: ordinary copy)
+            (void)hipGetLastError();
+            if (hipMemcpyAsync(dst[k], src[k], (size_t)bytes[k], hipMemcpyDefault, st) != hipSuccess) return COMBAT_ELAUNCH;
+            continue;
+        }
+        if (at.type == hipMemoryTypeHost && at.devicePointer) {
+            dev_src = at.devicePointer;
+        } else if (at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged) {
+            // pageable host memory ("unregistered": the query succeeds for it), anything unknown: never hand it to a kernel
+            if (hipMemcpyAsync(dst[k], src[k], (size_t)bytes[k], hipMemcpyDefault, st) != hipSuccess) return COMBAT_ELAUNCH;
+            continue;
+        }
+        a.dst[n] = dst[k];
+        a.src[n] = dev_src;
+        a.bytes[n] = bytes[k];
+        if (bytes[k] > most) most = bytes[k];
+        ++n;
+    }
+    if (!n) return COMBAT_OK;
+    long bx = (most / 16 + 255) / 256;
+    if (bx < 1) bx = 1;
+    if (bx > 512) bx = 512;
+    COMBAT_LAUNCH(copy3_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, st, a);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
 extern "C" int combat_log_terms(const float *x, const float *xb, const float *mse_partial, int32_t n, int32_t hw,
                                 const float *detector_logits, double *acc2, double *hits, void *stream) {
     COMBAT_PLAN_HOOK(combat_log_terms, x, xb, mse_partial, n, hw, detector_logits, acc2, hits);

@@ -1319,9 +1319,24 @@ class UnetEngine(NetEngine):
         self.zeros = torch.zeros(64 * 8, dtype=f32, device=self.device)
 
     def _refresh_extra(self):
+        if self.bias8_taken:          # the caller copied it with its own small copies (small_refresh_copy)
+            self.bias8_taken = False
+            return
         b = self.bias["upconv0_0"]
         if b is not None:
             self.out_bias8[: b.numel()].copy_(b)
+
+    bias8_taken = False
+
+    def small_refresh_copy(self):
+        """(dst pointer, src pointer, bytes) of the one small copy the next refresh() would issue by itself (the output
+        layer's bias into its 8-channel form), for a caller that batches it with copies of its own (combat_copy3) --
+        or None if the operands are current.  The next refresh() then skips it."""
+        b = self.bias["upconv0_0"]
+        if not self.weights_dirty or b is None:
+            return None
+        self.bias8_taken = True
+        return self.out_bias8.data_ptr(), b.data_ptr(), 4 * b.numel()
 
     def input(self, slot: Slot) -> torch.Tensor:
         return slot.buf("x", (slot.N, slot.hw, slot.hw, 8))

@@ -356,10 +356,26 @@ class AlternatedStep:
             aug_ptr.append(self.tab_f[i].data_ptr() if a is not None else None)
         h_k1[0].copy_(torch.from_numpy(trigger.gaussian_kernel1d(rnd.sigma_c, opt.kernel_size)))
         h_k1[1].copy_(torch.from_numpy(trigger.gaussian_kernel1d(rnd.sigma_g, opt.kernel_size)))
-        self.tab.copy_(hs["raw"], non_blocking=True)
+        # ---- the step's small copies as ONE launch (combat_copy3): table (pinned host memory, read through its device
+        # mapping), batch, and the generator's re-packed output bias
+        extra = self.eG.small_refresh_copy() if hasattr(self.eG, "small_refresh_copy") else None
+        direct = inputs.dtype == f32 and inputs.is_contiguous() and (inputs.is_cuda or inputs.is_pinned()) and \
+            tuple(inputs.shape) == tuple(self.inputs.shape)
+        if os.environ.get("COMBAT_NO_COPY3") == "1":          # A/B: three asynchronous copies
+            self.tab.copy_(hs["raw"], non_blocking=True)
+            direct = False
+            if extra:
+                self.eG.bias8_taken = False
+        else:
+            ops.check(lib.combat_copy3(self.tab.data_ptr(), hs["raw"].data_ptr(), hs["raw"].numel(),
+                                       self.inputs.data_ptr() if direct else None, inputs.data_ptr() if direct else None,
+                                       inputs.numel() * 4 if direct else 0,
+                                       extra[0] if extra else None, extra[1] if extra else None, extra[2] if extra else 0, st),
+                      "combat_copy3")
         hs["done"] = torch.cuda.Event()
         hs["done"].record()
-        self.inputs.copy_(inputs, non_blocking=True)
+        if not direct:
+            self.inputs.copy_(inputs, non_blocking=True)
         eC, eG, eK, eF, pl = self.eC, self.eG, self.eK, self.eF, self.pl
         for e in (eC, eG, eK) + ((eF,) if eF is not None else ()):
             e.refresh()

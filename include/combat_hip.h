@@ -424,6 +424,11 @@ int combat_nchw_to_nhwc_bf16(const float *x, int32_t n, int32_t c, int32_t h, in
 int combat_relu_mask(const void *g, const void *act, int64_t elements, void *out, void *stream);
 /* hipMemsetAsync(ptr, 0, bytes): gradient buffers are accumulated into and must start at zero */
 int combat_memset_zero(void *ptr, int64_t bytes, void *stream);
+/* up to three byte copies (bytes == 0: skipped) as ONE kernel launch on `stream`; a source in pinned host memory is read
+ * through its device mapping, an unmapped / unknown one falls back to hipMemcpyAsync.  The alternated step's table, batch
+ * and re-packed bias at a step boundary (train_generator.py:169-171: inputs.to(device) and the per-step draws). */
+int combat_copy3(void *dst0, const void *src0, int64_t bytes0, void *dst1, const void *src1, int64_t bytes1,
+                 void *dst2, const void *src2, int64_t bytes2, void *stream);
 /* column sums of a bf16 [rows][C] tensor into fp32 out[c_out] (overwritten): conv bias gradient */
 int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream);
 /* The logged-only terms of one step in one launch (train_generator.py:234-247): acc2[0] += MSE(inputs_bd, inputs) from the

@@ -1117,6 +1117,30 @@ def test_bn_eval_fold(ops):
     assert rel_l2(x * sc.cpu() + sh.cpu(), F.batch_norm(x, rm, rv, gm, bt, training=False)) < 1e-6
 
 
+def test_copy3_one_launch_for_three_copies(ops):
+    """combat_copy3: device and pinned-host sources (the latter read through the device mapping), unaligned pointers and
+    lengths, skipped entries, an unpinned host source (falls back to an ordinary copy)."""
+    from combat_amd._lib import lib
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.randn(300_001, generator=g(601))                       # 1.2 MB, length not a multiple of 16 bytes
+    a_dev, a_pin, a_host = a.cuda(), a.clone().pin_memory(), a.clone()
+    small = torch.arange(3, dtype=torch.float32).cuda()
+    raw = torch.randint(0, 255, (4099,), dtype=torch.uint8, generator=g(602)).pin_memory()
+    d0, d1, d2 = torch.zeros_like(a_dev), torch.zeros(8, device="cuda"), torch.zeros(4099, dtype=torch.uint8, device="cuda")
+    ops.check(lib.combat_copy3(d0.data_ptr(), a_pin.data_ptr(), a.numel() * 4, d1.data_ptr(), small.data_ptr(), 12,
+                               d2.data_ptr(), raw.data_ptr(), 4099, st), "copy3")
+    torch.cuda.synchronize()
+    assert torch.equal(d0.cpu(), a) and torch.equal(d1.cpu(), torch.tensor([0., 1., 2., 0., 0., 0., 0., 0.])) and torch.equal(d2.cpu(), raw)
+    # unaligned device views, a skipped entry, an unpinned host source
+    e0, e2 = torch.zeros(300_001, device="cuda"), torch.zeros_like(a_dev)
+    ops.check(lib.combat_copy3(e0[1:].data_ptr(), a_dev[3:].data_ptr(), (a.numel() - 3) * 4, None, None, 0,
+                               e2.data_ptr(), a_host.data_ptr(), a.numel() * 4, st), "copy3")
+    torch.cuda.synchronize()
+    assert torch.equal(e0[1:-2].cpu(), a[3:]) and float(e0[0]) == 0.0 and torch.equal(e2.cpu(), a)
+    assert lib.combat_copy3(None, a_dev.data_ptr(), 16, None, None, 0, None, None, 0, st) == -1     # bytes without a destination
+    assert lib.combat_copy3(None, None, 0, None, None, 0, None, None, 0, st) == 0                   # nothing to do
+
+
 # ---------------------------------------------------------------- UNet glue
 
 

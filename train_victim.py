@@ -35,8 +35,8 @@ def train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt):
     for batch_idx, (inputs, targets, poisoned) in enumerate(train_dl):
         step.run(inputs.to(opt.device, non_blocking=True), targets, poisoned, lr=optimizerC.param_groups[0]["lr"])
         total += inputs.shape[0]
-        if step.wanet and not batch_idx % 5:       # train_victim_wanet.py:127-133 (every fifth batch with a poisoned image)
-            pair = step.poisoned_pair() or pair
+        if step.wanet and (not batch_idx % 5 or pair is None):   # train_victim_wanet.py:127-133: every fifth batch with a poisoned
+            pair = step.poisoned_pair() or pair                   # image (until one is found: any batch, so that an epoch logs a grid)
         last = batch_idx == len(train_dl) - 1 or (opt.max_steps and batch_idx + 1 >= opt.max_steps)
         if batch_idx % max(1, opt.log_interval) == 0 or last:
             m = step.read_metrics()
