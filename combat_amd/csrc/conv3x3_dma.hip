@@ -531,9 +531,9 @@ __device__ __forceinline__ void conv3x3_ws_body(const DmaParams &p) {
     };
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void_t *)smem);
 #define COMBAT_DMA16(rs, lds_addr, voff)                                                         \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory")
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0")
 #define COMBAT_DMA4(rs, lds_addr, voff)                                                          \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory")
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs) : "memory", "m0")
     // ---- the filter bank, once: wave w brings rows 8 w .. 8 w + 7 of every tap (dgrad walks the taps mirrored)
     {
         const u32x4_t wrs = rsrc_words(a.wpack, p.w_bytes);

@@ -123,7 +123,7 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_builtin, (lds_void_t *)(smem + (lds_off) + wid * 1024), 16, voff, 0, 0, 0)
 #else
 #define COMBAT_W3_DMA(rs_builtin, rs_words, lds_off, voff) \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds0_l + (unsigned)(lds_off)), "v"(voff), "s"(rs_words##_l) : "memory")
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds0_l + (unsigned)(lds_off)), "v"(voff), "s"(rs_words##_l) : "memory", "m0")
 #endif
 
     // ---- DMA bookkeeping that does not depend on the patch: this lane's row of every piece it issues

@@ -50,6 +50,32 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, group=None) -> None:
         dist.broadcast(t.data, src, group=group)
 
 
+def average_bn_buffers(module: torch.nn.Module, group=None) -> int:
+    """BatchNorm running statistics are rank-local during training (each rank normalises with the statistics of its
+    own 128-image shard: DDP's default), so after an epoch the replicas' `running_mean` / `running_var`
+    differ slightly while every parameter is bit-identical.  Before anything reads them -- the per-epoch evaluation,
+    whose counters are summed over ranks, and the checkpoint rank 0 writes -- they are AVERAGED over the ranks (the
+    exponential average is linear in the batch statistics, so the mean of the ranks' running means is the running mean
+    of the mean batch statistic; `num_batches_tracked` is equal everywhere).  Every rank then evaluates, and rank 0
+    saves, the same model.  Returns the number of buffers exchanged (0 for a single process)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return 0
+    bufs = [b for name, b in module.named_buffers() if name.endswith(("running_mean", "running_var"))]
+    if not bufs:
+        return 0
+    flat = torch.cat([b.detach().reshape(-1).float() for b in bufs])
+    dist.all_reduce(flat, group=group)
+    flat /= dist.get_world_size(group)
+    o = 0
+    for b in bufs:
+        b.data.copy_(flat[o:o + b.numel()].view_as(b))
+        o += b.numel()
+    eng = module.__dict__.get("_eng")
+    if eng is not None:
+        eng.mark_weights_dirty()          # the folded eval-mode scale / shift tables are stale
+    return len(bufs)
+
+
 def bucket_ranges(total: int, marks: Sequence[int], min_elems: int = 1 << 20) -> List[Tuple[int, int]]:
     """Split [0, total) at the given offsets (layer boundaries of the flat gradient buffer, ascending)
     into contiguous buckets of at least `min_elems` elements, returned in REVERSE order -- the order in

@@ -580,7 +580,23 @@ def _pow2_part(pq: int, cap: int = 32) -> int:
 class NetEngine:
     """Shared machinery: parameters, packed operands, scratch, slots."""
 
-    flush_at_marks = False   # set (before any backward plan is built) by a data-parallel step: see Plan.flush_at_marks
+    _flush_at_marks = False
+
+    @property
+    def flush_at_marks(self) -> bool:
+        """Set by a data-parallel step (see Plan.flush_at_marks).  Backward plans copy it when they are built and are
+        cached per slot, and an engine is shared by every step object of its module: changing the value drops the
+        cached backward plans, so that a plan built for a single-rank step is never replayed under all-reduce marks."""
+        return self._flush_at_marks
+
+    @flush_at_marks.setter
+    def flush_at_marks(self, value: bool) -> None:
+        value = bool(value)
+        if value != self._flush_at_marks:
+            for slot in getattr(self, "slots", {}).values():
+                for k in [k for k in slot.plans if k.startswith("bwd")]:
+                    del slot.plans[k]
+        self._flush_at_marks = value
 
     def __init__(self, module: torch.nn.Module):
         self.module = module
@@ -654,8 +670,8 @@ class NetEngine:
         n, p, q, c = dst.shape
         pq, m = p * q, n * p * q
         a = ops.conv_args(src, dst, pc, 0, workspace=plan.workspace(src.device), **conv_kw)
-        _tile_preference(a)
         a.stats_kind = 1 | (BATCH_STATS_ROWS if groups == 1 else 0)    # (the row layout depends on it)
+        _tile_preference(a)      # (after every field the tile choice reads -- the epilogue flavour -- is final)
         rows, rpi = ops.conv_stats_layout(a)
         fused = (groups == 1) or (rpi > 0)
         st = slot.norm.get(key)
@@ -716,9 +732,9 @@ class NetEngine:
         mask = Affine(st.scale, st.shift, group_stride, True, slope)
         a = ops.conv_args(dy, dz, pc, 1, add_pre=add_pre, mask_x=x_pre, mask=mask, workspace=plan.workspace(dy.device),
                           shortcut=shortcut)
-        _tile_preference(a)
         a.stats_kind = 2 | (BATCH_STATS_ROWS if groups == 1 else 0)
         a.xh_mean, a.xh_rstd = st.mean.data_ptr(), st.rstd.data_ptr()
+        _tile_preference(a)      # (after stats_kind / xh_*: the tile query and the launch must see the same flavour)
         rows, rpi = ops.conv_stats_layout(a)
         fused = (groups == 1) or (rpi > 0)
         part, rpg = None, 0

@@ -374,6 +374,10 @@ class AlternatedStep:
                       "combat_copy3")
         hs["done"] = torch.cuda.Event()
         hs["done"].record()
+        # combat_copy3 reads a pinned host batch through its device mapping, which torch's caching host allocator cannot
+        # see (no event is recorded against the block, unlike copy_(non_blocking=True)): keep the batch alive in this
+        # staging set until `done` has completed, so a caller may drop its pinned tensor right after run()
+        hs["inputs_ref"] = inputs if direct and not inputs.is_cuda else None
         if not direct:
             self.inputs.copy_(inputs, non_blocking=True)
         eC, eG, eK, eF, pl = self.eC, self.eG, self.eK, self.eF, self.pl

@@ -97,6 +97,74 @@ def main():
     res["replicas_bit_identical_after_2_steps"] = ident
     res["finite"] = bool(all(np.isfinite(v) for v in st.read_metrics().values()))
     res["len_loader_equal"] = True
+    del st, netc, netg, clean, netf
+
+    # ---- the other data-parallel steps: ClassifierStep behind a UNet and behind a GridGenerator (bucketed
+    # all-reduce at the plan's marks), WanetStep (surrogate through its marks + the grid head's gradient range)
+    class WOpt(Opt):
+        s, grid_rescale = 2, 0.15
+
+    def gather_equal(buf):
+        got = [torch.zeros_like(buf).cpu() for _ in range(world)]
+        dist.all_gather(got, buf.cpu())
+        return bool(torch.equal(got[0], got[1]))
+
+    pz = torch.zeros(b, dtype=torch.bool)
+    pz[:3] = True                                               # three poisoned target-class images per rank
+    for tag, gen_ctor, opt in (("clf_unet", lambda: nets.UnetGenerator(None), Opt()),
+                               ("clf_grid", lambda: nets.GridGenerator(WOpt()), WOpt()),
+                               ("clf_clean", None, Opt())):
+        def fresh():
+            torch.manual_seed(0)
+            c = nets.PreActResNet18().cuda()
+            g_ = None
+            if gen_ctor is not None:
+                torch.manual_seed(2)
+                g_ = gen_ctor().cuda().eval()
+            return c, g_
+        netc, netg = fresh()
+        torch.manual_seed(555 + rank)                           # (the blur sigma is drawn from torch's global stream)
+        s1 = step_mod.ClassifierStep(netc, opt, netg)
+        s1.run(x.cuda(), t, pz if netg is not None else None)
+        torch.cuda.synchronize()
+        g_single = s1.eC.fp.grad.detach().clone()
+        del s1, netc, netg
+        netc, netg = fresh()
+        torch.manual_seed(555 + rank)
+        sd = step_mod.ClassifierStep(netc, opt, netg, process_group=dist.group.WORLD)
+        sd.run(x.cuda(), t, pz if netg is not None else None)
+        torch.cuda.synchronize()
+        singles = [torch.zeros_like(g_single).cpu() for _ in range(world)]
+        dist.all_gather(singles, g_single.cpu())
+        res[tag + "_grad_sum_vs_singles"] = rel(sd.eC.fp.grad.cpu(), singles[0] + singles[1])
+        res[tag + "_grad_identical_across_ranks"] = gather_equal(sd.eC.fp.grad)
+        sd.run(x.cuda(), t, pz if netg is not None else None)
+        torch.cuda.synchronize()
+        res[tag + "_replicas_bit_identical_after_2_steps"] = gather_equal(sd.eC.fp.flat) and gather_equal(sd.eC.fp.mom)
+        del sd, netc, netg
+
+    torch.manual_seed(0)
+    netc = nets.PreActResNet18().cuda()
+    torch.manual_seed(1)
+    clean = nets.PreActResNet18().cuda().eval()
+    torch.manual_seed(2)
+    netg = nets.GridGenerator(WOpt()).cuda()
+    torch.manual_seed(3)
+    netf = nets.FrequencyModel(2, 3, 32).cuda().eval()
+    sw = step_mod.WanetStep(netc, netg, clean, netf, WOpt(), process_group=dist.group.WORLD)
+    sw.keep_grads = True
+    sw.run(x.cuda(), t, rnd[0])
+    torch.cuda.synchronize()
+    lo, hi = sw.eG.head_grad_range()
+    res["wanet_head_grad_identical_across_ranks"] = gather_equal(sw.eG.fp.grad[lo:hi])
+    res["wanet_head_grad_nonzero"] = bool(float(sw.eG.fp.grad[lo:hi].abs().sum()) > 0)
+    outside = torch.cat([sw.eG.fp.grad[:lo], sw.eG.fp.grad[hi:]])
+    res["wanet_grad_outside_head_range_is_zero"] = bool(float(outside.abs().max()) == 0.0) if outside.numel() else True
+    res["wanet_gradC_identical_across_ranks"] = gather_equal(sw.eC.fp.grad)
+    sw.run(x.cuda(), t, rnd[1])
+    torch.cuda.synchronize()
+    res["wanet_replicas_bit_identical_after_2_steps"] = all(
+        gather_equal(buf) for eng in (sw.eC, sw.eG) for buf in (eng.fp.flat, eng.fp.mom))
     with open(os.path.join(out_dir, "rank%d.json" % rank), "w") as f:
         json.dump(res, f)
     dist.barrier()

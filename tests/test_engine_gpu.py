@@ -875,6 +875,41 @@ def test_alternated_step_runs_with_sampled_randomness_and_empty_poison(mods):
     assert st2._side is st._side and st._side is not None
 
 
+def test_step_keeps_a_dropped_pinned_batch_alive(mods):
+    """combat_copy3 reads a pinned host batch through its device mapping, unseen by torch's caching
+    host allocator.  A caller that drops its per-batch pin_memory() tensor right after run() (a DataLoader with
+    pin_memory=True) must not have the block recycled under the device: the staging set holds the tensor until the
+    copy's event has completed.  Here the block would be handed out again and overwritten at once."""
+    step_mod = mods["step"]
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randint(0, 256, (16, 3, 32, 32), generator=gen).float() / 255 - 0.5) / 0.5
+    t = torch.randint(0, 10, (16,), generator=gen)
+    t[:4] = 0
+    rnd = lambda: step_mod.StepRandomness(2, 0.4, 0.7, [None] * 5)
+    outs = []
+    for pinned in (False, True):
+        netc, clean, netg, netf = _build(mods, [0, 1, 2, 3])
+        st = step_mod.AlternatedStep(netc.cuda(), netg.cuda(), clean.cuda().eval(), netf.cuda().eval(), Opt())
+        torch.cuda.synchronize()
+        if pinned:
+            xb = x.clone().pin_memory()
+            ptr = xb.data_ptr()
+            blocker = torch.cuda._sleep(200_000_000) if hasattr(torch.cuda, "_sleep") else None   # device busy: the copy runs late
+            st.run(xb, t, rnd())
+            held = st._stage[(st._stage_i - 1) % st.kStage]["inputs_ref"]
+            assert held is not None and held.data_ptr() == ptr
+            del xb, held
+            junk = [torch.full((16, 3, 32, 32), 9.0).pin_memory() for _ in range(4)]    # would reuse a freed block
+            assert all(j.data_ptr() != ptr for j in junk)
+        else:
+            st.run(x.cuda(), t, rnd())
+        torch.cuda.synchronize()
+        outs.append((st.inputs.clone(), st.read_metrics()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[1][0].cpu(), x)
+    for k in ("loss_ce_sum", "loss_l2_sum", "clean_model_loss_sum"):
+        assert abs(outs[0][1][k] - outs[1][1][k]) <= 1e-5 * max(1.0, abs(outs[0][1][k])), k
+
+
 def test_classifier_step_metrics_cover_ragged_batches(mods):
     """CIFAR-10's last batch is ragged (50000 % 128 = 80); ClassifierStep keeps a slot,
     plans and loss / accuracy cells per batch size, and read_metrics sums (and resets) all of them."""

@@ -457,6 +457,15 @@ def _dp_worker(rank, world, port, tmp):
         dist.all_gather(allids, ids)
         ok = ok and len(ids) == 26 and len(dl) == 4
         ok = ok and set(torch.cat(allids).tolist()) == set(range(51))   # disjoint (one wrapped sample), complete epoch shards
+    # BatchNorm running statistics are rank-local in training and averaged before evaluation / checkpoint
+    bn = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 1), torch.nn.BatchNorm2d(4))
+    with torch.no_grad():
+        bn[1].running_mean.fill_(1.0 + rank)
+        bn[1].running_var.fill_(2.0 + 2 * rank)
+        bn[1].num_batches_tracked.fill_(7)
+    moved = cdist.average_bn_buffers(bn)
+    ok = ok and moved == 2 and torch.equal(bn[1].running_mean, torch.full((4,), 1.5)) and \
+        torch.equal(bn[1].running_var, torch.full((4,), 3.0)) and int(bn[1].num_batches_tracked) == 7
     open(os.path.join(tmp, "ok%d" % rank), "w").write(str(bool(ok)))
     dist.destroy_process_group()
 

@@ -47,6 +47,7 @@ def train(netC, optimizerC, schedulerC, train_dl, tf_writer, epoch, opt, step=No
 def eval(netC, optimizerC, schedulerC, test_dl, best_clean_acc, tf_writer, epoch, opt):
     print(" Eval:")
     netC.eval()
+    cdist.average_bn_buffers(netC)    # data parallel: one model on every rank and in the checkpoint (combat_amd/dist.py)
     n = correct = 0
     for batch_idx, (inputs, targets) in enumerate(test_dl):
         with torch.no_grad():

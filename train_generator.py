@@ -98,6 +98,7 @@ def eval(netC, optimizerC, schedulerC, netG, optimizerG, schedulerG, netF, clean
          best_F_acc, best_clean_model_acc, best_clean_model_bd_ba, best_clean_model_bd_asr, tf_writer, epoch, opt):
     print(" Eval:")
     netC.eval()
+    cdist.average_bn_buffers(netC)    # data parallel: one model on every rank and in the checkpoint (combat_amd/dist.py)
     netG.eval()
     clean_model.eval()
     c = dict(clean_n=0, bd_n=0, clean=0, bd=0, F=0, cm=0, cm_ba=0, cm_asr=0)

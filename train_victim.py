@@ -53,6 +53,7 @@ def train(netC, optimizerC, schedulerC, netG, train_dl, tf_writer, epoch, opt):
 def eval(netC, optimizerC, schedulerC, netG, test_dl, best_clean_acc, best_bd_acc, tf_writer, epoch, opt):
     print(" Eval:")
     netC.eval()
+    cdist.average_bn_buffers(netC)    # data parallel: one model on every rank and in the checkpoint (combat_amd/dist.py)
     n = nb = correct = bd = 0
     for batch_idx, batch in enumerate(test_dl):
         inputs, targets = batch[0].to(opt.device), batch[1].to(opt.device)
