@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "images/sec per alternated generator+surrogate step, CIFAR-10 bs=128, 1/2/4/8 GPU"
 PEAK_BF16_TFLOPS = 2500.0
+STEP_GFLOP = 1493.95      # algorithmic minimum of one alternated step at B = 128
 def _pmc_traffic_files():
     """profiles/rNN_<tag>_pmc_hbm_traffic.csv, newest (highest round, then tag) first."""
     import glob
@@ -144,7 +145,7 @@ def conv_flops(a):
     pix = a.N * a.P * a.Q if a.mode == 0 else a.N * a.H * a.W
     fl = 2.0 * pix * pc.K * pc.c_real * pc.taps
     if a.src2:      # the block's 1x1 shortcut rides along (combat_conv_args.src2): its input gradient's work too
-        pc2 = a._keepalive[-1][1]
+        pc2 = a._keepalive[15][1]
         fl += 2.0 * pix * pc2.K * pc2.c_real * pc2.taps
     return fl
 
@@ -182,7 +183,7 @@ def shape_key(src_hw, c, k, r, stride):
 def roofline_from(prof):
     from combat_amd._lib import ConvArgs, lib
     import ctypes
-    groups, per_shape = {}, {}
+    groups, per_shape, per_shape_unet = {}, {}, {}
     for what, a, e0, e1 in prof:
         sec = e0.elapsed_time(e1) * 1e-3
         if isinstance(a, ConvArgs):
@@ -199,12 +200,14 @@ def roofline_from(prof):
         else:
             key, kind = shape_key(a.H, a.c_real, a.k_real, a.R, a.stride), "wgrad"
             if what.endswith(".reduce"):     # the deferred reduction of a weight gradient: time, no work, no launch of its own
-                if what.startswith("preact."):
-                    per_shape.setdefault(key, {}).setdefault(kind, [0.0, 0.0, 0])[1] += sec
+                tab = per_shape if what.startswith("preact.") else (per_shape_unet if what.startswith("unet.") else None)
+                if tab is not None:
+                    tab.setdefault(key, {}).setdefault(kind, [0.0, 0.0, 0])[1] += sec
                 continue
             fl = wgrad_flops(a)
-        if what.startswith("preact."):
-            d = per_shape.setdefault(key, {}).setdefault(kind, [0.0, 0.0, 0])
+        tab = per_shape if what.startswith("preact.") else (per_shape_unet if what.startswith("unet.") else None)
+        if tab is not None:
+            d = tab.setdefault(key, {}).setdefault(kind, [0.0, 0.0, 0])
             d[0] += fl
             d[1] += sec
             d[2] += 1
@@ -220,23 +223,38 @@ def roofline_from(prof):
     fam, (fl, sec, cnt) = max(fams.items(), key=lambda kv: kv[1][1])
     achieved = fl / sec / 1e12
     traffic, traffic_file = pmc_traffic(fam + "<")
-    shapes = {}
-    for key, kinds in sorted(per_shape.items()):
-        shapes[key] = {kind: {"launches": c, "us": round(s_ / c * 1e6, 2), "tflops": round(f / s_ / 1e12, 1),
-                              "frac": round(f / s_ / 1e12 / PEAK_BF16_TFLOPS, 4)}
-                       for kind, (f, s_, c) in sorted(kinds.items())}
+    def table(tab):
+        return {key: {kind: {"launches": c, "us": round(s_ / c * 1e6, 2), "tflops": round(f / s_ / 1e12, 1),
+                             "frac": round(f / s_ / 1e12 / PEAK_BF16_TFLOPS, 4)}
+                      for kind, (f, s_, c) in sorted(kinds.items())} for key, kinds in sorted(tab.items())}
+    shapes, shapes_unet = table(per_shape), table(per_shape_unet)
+    traffic_pass_ms = None
+    if traffic_file:        # the bench line of the profiling pass the counters were collected in (same file prefix)
+        try:
+            with open(os.path.join(ROOT, "profiles", traffic_file.replace("_pmc_hbm_traffic.csv", "_bench.json"))) as f:
+                traffic_pass_ms = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1]).get("ms_per_step")
+        except (OSError, ValueError, IndexError):
+            pass
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
         "traffic": traffic,
         "traffic_unit": "HBM bytes per launch, launch-weighted over the instantiations (rocprofv3 PMC passes, "
                         "profiles/%s)" % traffic_file,
+        "traffic_source": {"file": "profiles/%s" % traffic_file if traffic_file else None,
+                           "pass_ms_per_step": traffic_pass_ms,
+                           "note": "counters come from a committed profiling pass of this same command, not from this "
+                                   "run: PMC collection needs rocprofv3 around the process"},
         "kernel": fam + " (all tile instantiations)", "launches": cnt, "avg_launch_us": round(sec / cnt * 1e6, 2),
         "gflop_per_launch": round(fl / cnt / 1e9, 3),
         "all_conv_tiles": {TILE_NAMES.get(t, str(t)): {"launches": c, "avg_us": round(s_ / c * 1e6, 2),
                                                       "tflops": round(f / s_ / 1e12, 1)}
                            for t, (f, s_, c) in sorted(groups.items())},
         "per_shape": shapes,
+        "per_shape_unet": shapes_unet,
+        "per_shape_unet_note": "the UNet generator's convolutions (networks/models.py:275-314), same keys; its 3-channel "
+                               "output layer and first layer count their REAL channels (3), so their fractions are "
+                               "small by construction",
         "per_shape_note": "PreActResNet18 convolutions (surrogate + clean model plans), keyed 'RxS stride Cin->Cout "
                           "@input HxW'; wgrad = weight-gradient launch incl. its partial-sum reduction launch; the 1x1 "
                           "stride-2 shortcuts' input gradients ride along in the 3x3 stride-2 dgrad launches (second "
@@ -497,6 +515,12 @@ def main():
         st.serial = Plan.serial = False
         if rank == 0:
             roof = roofline_from(prof)
+            if args.dataset == "cifar10":   # the WHOLE step against the MFMA peak: SURVEY 8(d)'s 1 493.95 GFLOP per 128-image step
+                ms = elapsed / args.steps * 1e3
+                roof["step_frac"] = round(STEP_GFLOP * world / (ms * 1e-3) / 1e3 / (PEAK_BF16_TFLOPS * world), 4)
+                roof["step_tflops"] = round(STEP_GFLOP / (ms * 1e-3) / 1e3, 1)
+                roof["step_frac_note"] = ("%.2f GFLOP algorithmic per 128-image step (SURVEY 8(d)) / ms_per_step of the timed "
+                                          "region / 2.5 PFLOP/s, per GPU" % STEP_GFLOP)
             roof["replay"] = "serial (one stream), HIP events around each convolution / weight-gradient launch, %d steps" % min(args.steps, 20)
             log("instrumented replay done: %s %.1f TFLOP/s" % (roof["kernel"], roof["achieved"]))
     if world > 1:

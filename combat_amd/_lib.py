@@ -34,6 +34,7 @@ class ConvArgs(C.Structure):
         ("workspace", c_vp), ("workspace_bytes", c_i64),
         ("tile", c_i32),
         ("src2", c_vp), ("wpack2", c_vp), ("kpad2", c_i32), ("rows_pad2", c_i32),
+        ("pro_act_dst", c_vp),
     ]
 
 

@@ -104,7 +104,36 @@ __device__ __forceinline__ void block_barrier() {
 //       wave tile: (4 + 4) instead of (2 + 4) fragment reads per 16 MFMAs), and a 256-pixel workgroup of four waves:
 //       512 workgroups for a 64 -> 64 layer on 32 x 32 maps = ONE round at two per CU, where the 128-pixel tiles need
 //       1.33 rounds at three.  Its epilogue runs as two 32-pixel halves with operand fetches issued after the loop.
-template <int BN, int TW, int HB, int NW, int RPW>
+// PRO: the input's per-channel normalisation + activation (combat_conv_args.pro_*: train-mode BatchNorm + ReLU in front
+//       of the convolution, preact_resnet.py:32,35) applied IN PLACE IN LDS after a halo patch has landed -- the
+//       operands still arrive by DMA, the raw tensor is read once, and no activated copy has to be materialised by a
+//       launch of its own in front of this one (combat_norm_act_fused: 25 dependent launches of a step).  Each wave
+//       transforms the pieces it DMA'd itself (its own counted wait covers them: no extra barrier), one 16-byte slot
+//       per lane: lane -> (row = piece row, channel group g = lane & 7), so a lane's eight (scale, shift) pairs are
+//       fixed per chunk; out-of-image rows stay the zeros the DMA wrote (the padding of the ACTIVATED tensor).  The
+//       next chunk's patch is transformed during taps 3..7 of the current one (it has landed by the counted wait of
+//       tap 3 and is first read after the barrier of tap 8); only the first chunk's pass is exposed.  The workgroups
+//       of channel tile 0 also write the activated interior of their patch to pro_act_dst (read back from LDS during
+//       the same taps): the tensor the weight gradient of this layer reads.
+// FLX:  >= 0: only epilogue flavour kEpiFlavours[FLX] is compiled into the kernel (the prologue's registers do not fit
+//       beside five epilogue bodies); -2: the run-time switch over all of them
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {      // f(integral_constant<int, I>) ... f(integral_constant<int, N - 1>)
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int HPW_>
+constexpr int pro_slot_pieces(int u) {   // pieces handled in the slot behind the barrier of tap u (u = 3..7)
+    constexpr int PPP = (HPW_ + 4) / 5;
+    if (u < 3 || u > 7) return 0;
+    const int rem = HPW_ - (u - 3) * PPP;
+    return rem <= 0 ? 0 : (rem < PPP ? rem : PPP);
+}
+
+template <int BN, int TW, int HB, int NW, int RPW, bool PRO = false, int FLX = -2>
 __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     using T = TileCfg<4 * RPW, BN, 4>;  // shape of ONE wave's share: RPW pixels x all BN channels (whatever NW is)
     using TE = TileCfg<128, BN, 4>;     // the epilogue's unit: 32 pixels x BN channels
@@ -114,10 +143,19 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     constexpr int WBYTES = BN * 128;        // one ring slot
     constexpr int HBYTES = G::HBYTES;
     constexpr int HPW = G::HPW;
+    static_assert(!PRO || (NW == 4 && RPW == 32), "the LDS prologue exists for the 128-pixel tiles");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const combat_conv_args &a = p.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // PRO: the (scale, shift) table is fetched ahead of every DMA and parked in LDS behind the weight ring
+    f32x4_t pt_sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, pt_sh = pt_sc;
+    if constexpr (PRO) {
+        if (tid * 4 < a.C) {
+            pt_sc = *reinterpret_cast<const f32x4_t *>(a.pro_scale + tid * 4);
+            pt_sh = *reinterpret_cast<const f32x4_t *>(a.pro_shift + tid * 4);
+        }
+    }
 #ifdef COMBAT_STAMPS
     const unsigned long long c_entry = __builtin_readcyclecounter();
     __builtin_amdgcn_sched_barrier(0);
@@ -218,6 +256,74 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
                                                      hvoff[j], cc * 128, 0, 0);
     };
     issue_h(0, 0);
+    // ---- PRO: this lane's slot of every piece it transforms (same rows as its DMA pieces; channel group g = lane & 7
+    // sits in LDS slot (g + rotation of the row) & 7), which of them lie inside the image, and where the interior
+    // ones go in pro_act_dst (channel tile 0 only; everything else gets an out-of-range offset: the store is dropped)
+    constexpr int kTA = PRO ? HPW : 1;
+    int taddr[kTA];
+    unsigned aoff[kTA], tvalid = 0;
+    float *const ptab = reinterpret_cast<float *>(smem + HB * HBYTES + 3 * WBYTES + 1024);
+    const float pslope = a.pro_slope;
+    __amdgpu_buffer_rsrc_t r_pact = srsrc;
+    if constexpr (PRO) {
+        r_pact = __builtin_amdgcn_make_buffer_rsrc(a.pro_act_dst, 0, a.pro_act_dst ? p.src_bytes : 0u, 0x00020000);
+        const int g = lane & 7;
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) {
+            const int row = (wid + NW * j) * 8 + (lane >> 3);
+            const int hx = row % G::HWP, t = row / G::HWP;
+            const int hy = t % G::HH, ti = t / G::HH;
+            const int rot = TW == 4 ? ((hx & 2) + ((hy & 1) << 2)) : (hx & 6);
+            taddr[j] = row * 128 + ((g + rot) & 7) * 16;
+            const int img = img0 + ti, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+            const bool ok = row < G::HROWS && hx < TW + 2 && img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            tvalid |= ok ? (1u << j) : 0u;
+            const bool interior = ok && hx >= 1 && hx <= TW && hy >= 1 && hy <= G::TH && tile_n == 0;
+            aoff[j] = interior ? (unsigned)((((img * H + iy) * W + ix) * C + g * 8) * 2) : kOob;
+        }
+        if (tid * 4 < C) {
+            *reinterpret_cast<f32x4_t *>(ptab + tid * 4) = pt_sc;
+            *reinterpret_cast<f32x4_t *>(ptab + C + tid * 4) = pt_sh;
+        }
+    }
+    auto pro_tab = [&](int cc, float (&sc)[8], float (&sh)[8]) __attribute__((always_inline)) {
+        const lds_f32_t *tab = (const lds_f32_t *)(smem + HB * HBYTES + 3 * WBYTES + 1024);
+        load8f_lds(tab + cc * 64 + (lane & 7) * 8, sc);
+        load8f_lds(tab + C + cc * 64 + (lane & 7) * 8, sh);
+    };
+    // act = lrelu(x * scale + shift): the arithmetic of norm_act_fused_kernel (norm.hip), bit for bit
+    // (two steps, so that a caller can issue the reads of several pieces before the first write: a write in between
+    // would keep the later reads behind it -- the compiler cannot tell the slots apart -- one LDS round trip per piece)
+    auto pro_read = [&](auto j_tag, const unsigned char *hbase) __attribute__((always_inline)) {
+        return *reinterpret_cast<const u32x4_t *>(hbase + taddr[decltype(j_tag)::value]);
+    };
+    auto pro_xform = [&](auto j_tag, const u32x4_t v, const float (&sc)[8], const float (&sh)[8], unsigned char *hbase) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value;
+        u32x4_t *q = reinterpret_cast<u32x4_t *>(hbase + taddr[j]);
+        float f[8];
+        unpack8v(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y = fmaf(f[e], sc[e], sh[e]);
+            f[e] = y > 0.f ? y : y * pslope;
+        }
+        const u32x4_t o = pack8v(f);
+        const bool ok = (tvalid >> j) & 1u;
+        u32x4_t w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = ok ? o[e] : v[e];     // (out-of-image rows: the zeros the DMA wrote)
+        *q = w;
+    };
+    auto pro_side = [&](auto j_tag, int cc, const unsigned char *hbase) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value;
+        const u32x4_t v = *reinterpret_cast<const u32x4_t *>(hbase + taddr[j]);
+        // (the chunk's byte offset goes into the VECTOR offset, not the scalar one: with an SGPR soffset the compiler
+        // sees no hazard in overwriting a 16-byte store's data registers right behind it -- GCNHazardRecognizer's
+        // rule for MUBUF stores wider than 8 bytes -- and on gfx950 the store then read registers the next piece's
+        // arithmetic had already reused: ~3 % wrong values in lanes 12-15 / 28-31 / 44-47 / 60-63, different ones
+        // from launch to launch.  With an immediate soffset the wait state is inserted.)
+        __builtin_amdgcn_raw_buffer_store_b128(v, r_pact, aoff[j] + (unsigned)(cc * 128), 0, 0);
+    };
 
     // ---- per-lane fragment read offsets: pixel fragment j at column offset dx, k-step ks
     int pa[2][T::FM][3];
@@ -362,14 +468,55 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     wait_vm_lgkm0<0>();      // the halo patch was issued last
     block_barrier();
     DSTAMP(1);
+    if constexpr (PRO) {     // the first chunk's patch: every wave its own pieces, then one more barrier (the only exposed pass)
+        float sc0[8], sh0[8];
+        pro_tab(0, sc0, sh0);
+        u32x4_t raw0[HPW];
+        static_for<0, HPW>([&](auto j_tag) __attribute__((always_inline)) { raw0[decltype(j_tag)::value] = pro_read(j_tag, halo); });
+        static_for<0, HPW>([&](auto j_tag) __attribute__((always_inline)) { pro_xform(j_tag, raw0[decltype(j_tag)::value], sc0, sh0, halo); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        block_barrier();
+    }
     read_frags(fpA, fwA, I0{}, I0{}, I0{});
     __builtin_amdgcn_sched_barrier(0);
 
+    // PRO, behind the barrier of tap t = 3..7: this wave's pieces [first, first + count) -- the CURRENT chunk's go to
+    // pro_act_dst (read back from LDS: the same schedule for every chunk), the NEXT chunk's patch (landed: the counted wait of tap 3 covers this wave's own halo
+    // pieces) is transformed; its table registers are loaded in the slot of tap 3 and live to the slot of tap 7
+    float nsc[8], nsh[8];
+    auto pro_slot = [&](auto t_tag, auto last_tag, auto hbuf_tag, int cc) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_tag)::value, hbuf = decltype(hbuf_tag)::value;
+        constexpr bool last = decltype(last_tag)::value;
+        constexpr int PPP = (HPW + 4) / 5, first = (t - 3) * PPP, count = pro_slot_pieces<HPW>(t);
+        if constexpr (count > 0) {
+            unsigned char *cur = halo + hbuf * HBYTES, *nxt = halo + (HB == 2 ? (hbuf ^ 1) : 0) * HBYTES;
+            if (!last && t == 3) pro_tab(cc + 1, nsc, nsh);
+            u32x4_t rawn[count];
+            if constexpr (!last)
+                static_for<0, count>([&](auto i_tag) __attribute__((always_inline)) {
+                    rawn[decltype(i_tag)::value] = pro_read(std::integral_constant<int, first + decltype(i_tag)::value>{}, nxt);
+                });
+            static_for<first, first + count>([&](auto j_tag) __attribute__((always_inline)) { pro_side(j_tag, cc, cur); });
+            if constexpr (!last)
+                static_for<0, count>([&](auto i_tag) __attribute__((always_inline)) {
+                    pro_xform(std::integral_constant<int, first + decltype(i_tag)::value>{}, rawn[decltype(i_tag)::value], nsc, nsh, nxt);
+                });
+        }
+    };
     auto chunk = [&](auto last_tag, auto hbuf_tag, int cc) __attribute__((always_inline)) {
         constexpr bool last = decltype(last_tag)::value;
         constexpr int hbuf = decltype(hbuf_tag)::value;
         using HBUF = std::integral_constant<int, hbuf>;
         using HNEXT = std::integral_constant<int, HB == 2 ? (hbuf ^ 1) : 0>;
+        // (counted waits: at the wait of tap t every LOAD issued behind W(t + 1) may stay in flight -- W(t + 2), and
+        // what the slots of taps t - 2 and t - 1 issued after their weight tile: the next patch, the epilogue
+        // operands.  PRO's pro_act_dst STORES are deliberately not in the count: loads complete in order among
+        // themselves, stores among themselves, but a store may be acknowledged before an older load has landed -- with
+        // the stores added to the allowance, the wait let taps 6..8 read weight tiles that were still in flight
+        // (wrong outputs on ~half the elements of some launches, right ones on others: found with the engine's step
+        // test, not with the stand-alone comparison).  With at most (younger loads) operations allowed in flight,
+        // W(t + 1) has landed whatever the stores do; the price is that the few stores of the previous slot must have
+        // been acknowledged by then, a position later.)
 #define COMBAT_DMA_POS(t)                                                                                    \
     {                                                                                                        \
         using TT = std::integral_constant<int, t>;                                                           \
@@ -386,6 +533,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
             else if (!last) issue_w(t + 3 - 9, cc + 1, t % 3);                                               \
             if (t == 0 && !last) issue_h(cc + 1, HNEXT::value);                                              \
             if (last && t == PF_T) epilogue_fetch();                                                         \
+            if constexpr (PRO) pro_slot(TT{}, last_tag, hbuf_tag, cc);                                       \
             __builtin_amdgcn_sched_barrier(0);                                                               \
             if (t < 8) read_frags(fpA, fwA, TN{}, I0{}, HBUF{});                                             \
             else read_frags(fpA, fwA, TN{}, I0{}, HNEXT{});                                                  \
@@ -417,6 +565,12 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     // ---- epilogue: accumulators -> this wave's fp32 LDS image (the operand images are dead once every
     // wave has passed the barrier) -> row-major items
     if constexpr (!WIDE) {
+        // One epilogue flavour per kernel (FLX): the operands that flavour never reads would be dead loads, the
+        // compiler would drop them, and the main loop's counted waits -- which allow EXACTLY epi_fetch()'s NPF
+        // loads in flight at taps PF_T + 1 / + 2 -- would let the weight tiles of taps 6 / 7 be read before they
+        // have landed (seen only with cold caches, inside the step: isolated launches passed 2 800 times).  Every
+        // fetched register is therefore "used" here, as in the kernels that carry all flavours.
+        if constexpr (FLX >= 0) epi_touch<TE>(epi);
         block_barrier();
 #ifdef COMBAT_ABL_NOEPI     // (ablation: one store per lane keeps the accumulators alive)
         {
@@ -428,7 +582,11 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
             if (s == 12345.678f) reinterpret_cast<float *>(const_cast<void *>(a.dst))[lane] = s;
         }
 #else
-        epi_finish<TE>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged, p.PQ, p.flavour, NW);
+        if constexpr (FLX >= 0)
+            epi_finish_fl<TE, kEpiFlavours[FLX < 0 ? 0 : FLX]>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged,
+                                                                 p.PQ, nullptr, EpiNoHook(), NW);
+        else
+            epi_finish<TE>(epi, smem, acc, a, dst_bytes, lane, wid, n0, (long)tile_m * NW + wid, ragged, p.PQ, p.flavour, NW);
 #endif
     } else {
         // two 32-pixel halves, one after the other (both halves' operand sets at once would be 136 registers on
@@ -460,6 +618,13 @@ template <int BN, int TW, int HB, int NW, int RPW>
 __global__ __launch_bounds__(64 * NW, NW == 8 || (RPW == 64 && HB == 2) ? 1 : 2)
 void conv3x3_dma_kernel(const DmaParams p) {
     conv3x3_dma_body<BN, TW, HB, NW, RPW>(p);
+}
+
+// the same with the input's normalisation + activation applied in LDS (PRO above), one epilogue flavour per instantiation
+template <int BN, int TW, int HB, int FLX>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_dma_pro_kernel(const DmaParams p) {
+    conv3x3_dma_body<BN, TW, HB, 4, 32, true, FLX>(p);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -816,9 +981,20 @@ int geo_tw(const combat_conv_args *a) {
     return 0;
 }
 
+// the in-LDS prologue (PRO in the kernel body): per-channel scale / shift + (leaky) ReLU in front of a forward
+// convolution whose epilogue is one of the two flavours a train-mode network uses behind it (plain / statistics)
+bool pro_ok(const combat_conv_args *a) {
+    static const bool off = getenv("COMBAT_NO_DMA_PRO") != nullptr;     // A/B: such launches fall back to the halo kernels
+    if (off) return false;
+    if (!a->pro_scale || !a->pro_shift || !a->pro_act || a->pro_group_stride != 0 || a->mode != 0) return false;
+    if (a->C > 512) return false;                                        // (the table's LDS: 2 x 512 floats)
+    const int fl = epi_flavour_of(*a);
+    return fl == 0 || fl == 2;
+}
+
 bool applicable(const combat_conv_args *a, int BN) {
     if (!(a->R == 3 && a->S == 3 && a->stride == 1 && a->pad == 1 && a->P == a->H && a->Q == a->W)) return false;
-    if (a->pro_scale || a->pro_act) return false;   // operands go straight to LDS: no prologue
+    if ((a->pro_scale || a->pro_act || a->pro_act_dst) && !pro_ok(a)) return false;   // (only the in-LDS prologue below)
     if (a->tanh_out) return false;   // (stays with the halo kernels)
     if (a->mask_x && a->act_dst) return false;   // one table pair travels with the operand prefetch
     if (a->C < 64 || (a->C & 63) || a->K % BN || a->kpad < 9 * a->C) return false;
@@ -872,10 +1048,39 @@ int launch_hb(const DmaParams &p, hipStream_t st) {
     return COMBAT_OK;
 }
 
+template <int BN, int TW, int HB, int FLX>
+int launch_pro_fl(const DmaParams &p, hipStream_t st) {
+    using G = DGeo<TW, 4, 32>;
+    constexpr int stage = HB * G::HBYTES + 3 * BN * 128 + 1024 + 2 * 512 * 4;   // (+ the prologue's table)
+    constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES;
+    constexpr int smem = stage > ep ? stage : ep;
+    auto kern = conv3x3_dma_pro_kernel<BN, TW, HB, FLX>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr_set = true;
+    }
+    COMBAT_LAUNCH(kern, dim3(p.tiles_m * p.tiles_n), dim3(256), smem, st, p);
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+template <int BN, int TW>
+int launch_pro(const DmaParams &p, hipStream_t st) {
+    if (p.flavour == 0) return p.nchunks == 1 ? launch_pro_fl<BN, TW, 1, 0>(p, st) : launch_pro_fl<BN, TW, 2, 0>(p, st);
+    if (p.flavour == 2) return p.nchunks == 1 ? launch_pro_fl<BN, TW, 1, 2>(p, st) : launch_pro_fl<BN, TW, 2, 2>(p, st);
+    return COMBAT_EINVAL;
+}
+
 template <int BN, int TW, int NW, int RPW = 32>
 int launch(const combat_conv_args *a, hipStream_t st) {
     DmaParams p;
     fill<TW, NW, RPW>(a, BN, p);
+    if (a->pro_scale) {
+        if constexpr (NW == 4 && RPW == 32) return launch_pro<BN, TW>(p, st);
+        else return COMBAT_EINVAL;
+    }
     return p.nchunks == 1 ? launch_hb<BN, TW, 1, NW, RPW>(p, st) : launch_hb<BN, TW, 2, NW, RPW>(p, st);
 }
 
@@ -903,6 +1108,7 @@ int tiles_m_of(const combat_conv_args *a, int bm = 128) {
 // tiles per CU (with one, there is nothing to overlap: the ring kernel's three co-resident workgroups do better)
 constexpr int kWsSmem = 9 * 64 * 128 + 2 * DGeo<16, 4, 32>::HBYTES + EpiCfg<TileCfg<128, 64, 4>>::LDS_BYTES + 3 * 64 * 4;
 bool ws_applicable(const combat_conv_args *a) {
+    if (a->pro_scale) return false;   // (the in-LDS prologue lives in the ring kernel)
     if (a->C != 64 || a->K != 64 || !applicable(a, 64) || geo_tw(a) != 16 || a->H % 8) return false;
     if (epi_flavour_of(*a) < 0) return false;   // (the generic epilogue body does not fit beside the persistent state: 44 spills)
     return (long)tiles_m_of(a) >= 2 * 256 || a->tile == COMBAT_TILE_S128x64;
@@ -955,6 +1161,7 @@ int conv3x3d_pick(const combat_conv_args *a) {
     if (a->tile == COMBAT_TILE_S128x64) return ws_applicable(a) ? a->tile : 0;
     if (a->tile) {
         const int bn = tile_bn(a->tile);
+        if (a->pro_scale && tile_bm(a->tile) != 128) return 0;
         if (a->tile == COMBAT_TILE_D256W64 && geo_tw(a) != 16) return 0;
         return bn && applicable(a, bn) && geo_th(a, tile_bm(a->tile)) ? a->tile : 0;
     }

@@ -457,6 +457,8 @@ extern "C" int combat_conv_gemm(const combat_conv_args *a, void *stream) {
     p.tiles_m = p.tiles_n = 0;
     hipStream_t st = as_stream(stream);
     const int tile = pick_tile(a);
+    // (the prologue's second output exists on the DMA-staged 3x3 kernel only: refuse rather than silently not write it)
+    if (a->pro_act_dst && tile != COMBAT_TILE_D128x64 && tile != COMBAT_TILE_D128x32) return COMBAT_EINVAL;
     if (tile == COMBAT_TILE_C8) return conv_c8_launch(a, st);
     if (tile == COMBAT_TILE_K8) return conv_k8_launch(a, st);
     if (tile == COMBAT_TILE_G128x64 || tile == COMBAT_TILE_G128x32) return conv_gather_dma_launch(a, st);

@@ -18,10 +18,24 @@ __device__ __forceinline__ void reduce_rows(const float *__restrict__ part, int 
     s1 = 0.0;
     s2 = 0.0;
     if (c >= C) return;
-    for (int r = ry; r < nrows; r += 4) {
-        const float *p = part + ((row0 + r) * 2) * (long)C + c;
-        s1 += (double)p[0];
-        s2 += (double)p[C];
+    // eight rows' loads in flight per thread (a plain loop waited out one L2 round trip per row: 64 of them for the
+    // 256 rows a batch-statistics layer leaves)
+    for (int r = ry; r < nrows; r += 32) {
+        float u[8], v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int rr = r + 4 * q < nrows ? r + 4 * q : r;
+            const float *p = part + ((row0 + rr) * 2) * (long)C + c;
+            u[q] = p[0];
+            v[q] = p[C];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (r + 4 * q < nrows) {
+                s1 += (double)u[q];
+                s2 += (double)v[q];
+            }
+        }
     }
 }
 
@@ -816,7 +830,7 @@ int fused_chunk(long pxg, int groups, int C) {
 const float *maybe_stage1(const float *partials, int groups, int &rows_per_group, int C, float *scratch,
                           int64_t scratch_bytes, hipStream_t st, int &err) {
     err = COMBAT_OK;
-    if (rows_per_group <= 2 * kStageRows) return partials;
+    if (rows_per_group <= 4 * kStageRows) return partials;     // (<= 256 rows: one launch, eight loads in flight per thread)
     const int64_t need = (int64_t)groups * kStageRows * 2 * C * sizeof(float);
     if (!scratch || scratch_bytes < need) {
         err = COMBAT_EINVAL;

@@ -19,7 +19,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import STATS_PER_WORKGROUP, TILE_D128x64, TILE_S128x64, CombatHipError, lib
+from ._lib import STATS_PER_WORKGROUP, TILE_D128x32, TILE_D128x64, TILE_S128x64, CombatHipError, ConvArgs, lib
 from .nets import UNET_LAYERS
 from .ops import Affine, PackedConv, bf16
 
@@ -473,6 +473,9 @@ def _tile_preference(a) -> None:
 
 
 FUSE_SHORTCUT = os.environ.get("COMBAT_NO_FUSED_SHORTCUT", "0") != "1"
+# train-mode BatchNorm + ReLU applied by the CONSUMING convolution in LDS (PreActEngine._forward_train_body); 0: A/B, the
+# round-3 form (one combat_norm_act_fused launch per BatchNorm)
+FUSED_PROLOGUE = os.environ.get("COMBAT_NO_FUSED_PROLOGUE", "0") != "1"
 
 
 def fuse_shortcut(dy, dx, pc: PackedConv, dy_sc, pc_sc: PackedConv):
@@ -710,6 +713,26 @@ class NetEngine:
                  self._scratch.numel() * 4)
         return st
 
+    def _lds_prologue_ok(self, src, pc: PackedConv) -> bool:
+        """Would a forward 3x3 convolution of `src` through `pc` with a per-channel BatchNorm + ReLU prologue and the
+        activated side output take the DMA-staged kernel that applies the prologue in LDS (combat_conv_args.pro_act_dst)?"""
+        if not FUSED_PROLOGUE or pc.R != 3 or pc.stride != 1:
+            return False
+        n, h, w, _ = src.shape
+        probe = getattr(self, "_pro_probe", None)
+        if probe is None:
+            t = torch.zeros(512, dtype=f32, device=self.device)
+            probe = self._pro_probe = Affine(t, t, 0, True, 0.0)
+        a = ConvArgs()
+        a.N, a.H, a.W, a.C = src.shape
+        a.P, a.Q, a.K = h, w, pc.Kc
+        a.R = a.S = 3
+        a.stride, a.pad, a.mode = 1, pc.pad, 0
+        a.src, a.dst, a.pro_act_dst = src.data_ptr(), src.data_ptr(), src.data_ptr()
+        a.wpack, a.kpad, a.rows_pad = pc.wf.data_ptr(), pc.kpad_f, pc.rows_f
+        a.pro_scale, a.pro_shift, a.pro_act = probe.scale.data_ptr(), probe.shift.data_ptr(), 1
+        return lib.combat_conv_pick_tile(ctypes.byref(a)) in (TILE_D128x64, TILE_D128x32)
+
     def _norm_act(self, plan: Plan, st: NormState, act_dst, slope: float):
         """The deferred finalize of `st` + its activation tensor, one launch."""
         q = st.pending
@@ -907,13 +930,23 @@ class PreActEngine(NetEngine):
         """Train mode: BatchNorm uses batch statistics, produced by the epilogue of the convolution that
         writes the normalised tensor.  relu(bn(.)) is then materialised once per BatchNorm ('b%d.a0' =
         block input through bn1, 'b%d.a1t' = conv1 output through bn2): the forward convolutions and
-        the weight-gradient passes that read it need no prologue and take their operands by LDS-DMA."""
+        the weight-gradient passes that read it need no prologue and take their operands by LDS-DMA.
+
+        Round 4 (FUSED_PROLOGUE): where the consumer is a 3x3 / stride-1 convolution, relu(bn(.)) is not a launch of
+        its own any more: the producer's statistics are finalised (per-channel scale / shift) and the CONSUMING
+        convolution applies them in LDS after its DMA'd patch has landed (combat_conv_args.pro_* on the DMA-staged
+        kernel), writing the activated tensor out on the side for its weight gradient (pro_act_dst).  The blocks with
+        a stride-2 first convolution + 1x1 shortcut still get their input materialised by combat_norm_act_fused."""
         n, hw = slot.N, slot.hw
         cur = slot.buf("stem", (n, hw, hw, 64))
+
+        def fuse(blk, src):    # does blk.conv1 read its raw input `src` with the in-LDS prologue?
+            return blk.sc is None and blk.stride == 1 and self._lds_prologue_ok(src, blk.conv1)
+
         first = self.blocks[0].bn1
         a0 = slot.buf("b0.a0", cur.shape)
-        self._conv_norm(P, slot, first.prefix, x, cur, self.stem, groups=1, gamma=first.gamma, beta=first.beta,
-                        running=(first.rm, first.rv, first.nbt), act_dst=a0)
+        st = self._conv_norm(P, slot, first.prefix, x, cur, self.stem, groups=1, gamma=first.gamma, beta=first.beta,
+                             running=(first.rm, first.rv, first.nbt), act_dst=None if fuse(self.blocks[0], cur) else a0)
         chw = hw
         for b, blk in enumerate(self.blocks):
             ohw = chw // blk.stride
@@ -927,16 +960,29 @@ class PreActEngine(NetEngine):
             out = slot.buf("b%d.out" % b, (n, ohw, ohw, blk.planes))
             nxt = self.blocks[b + 1].bn1 if b + 1 < len(self.blocks) else None
             a1 = slot.buf("b%d.a1t" % b, y1.shape)
-            self._conv_norm(P, slot, blk.bn2.prefix, a0, y1, blk.conv1, groups=1, gamma=blk.bn2.gamma,
-                            beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt), act_dst=a1)
+            fuse2 = self._lds_prologue_ok(y1, blk.conv2)
+            bn2 = dict(groups=1, gamma=blk.bn2.gamma, beta=blk.bn2.beta, running=(blk.bn2.rm, blk.bn2.rv, blk.bn2.nbt),
+                       act_dst=None if fuse2 else a1)
+            if fuse(blk, cur):     # conv1 normalises + activates its raw input in LDS and leaves a0 for its weight gradient
+                st2 = self._conv_norm(P, slot, blk.bn2.prefix, cur, y1, blk.conv1, **bn2,
+                                      pro=Affine(st.scale, st.shift, 0, True, 0.0), pro_act_dst=a0)
+            else:
+                st2 = self._conv_norm(P, slot, blk.bn2.prefix, a0, y1, blk.conv1, **bn2)
             if blk.sc is not None:      # shortcut + first convolution: one launch (both read a0)
                 P.merge_convs(i_sc)
+            # conv2 is 3x3 / stride 1 in every block: relu(bn2(y1)) in LDS, a1 on the side
+            c2 = dict(add_post=resid)
+            src2 = a1
+            if fuse2:
+                c2.update(pro=Affine(st2.scale, st2.shift, 0, True, 0.0), pro_act_dst=a1)
+                src2 = y1
             if nxt is not None:
                 a0 = slot.buf("b%d.a0" % (b + 1), out.shape)
-                self._conv_norm(P, slot, nxt.prefix, a1, out, blk.conv2, groups=1, gamma=nxt.gamma, beta=nxt.beta,
-                                running=(nxt.rm, nxt.rv, nxt.nbt), add_post=resid, act_dst=a0)
+                st = self._conv_norm(P, slot, nxt.prefix, src2, out, blk.conv2, groups=1, gamma=nxt.gamma, beta=nxt.beta,
+                                     running=(nxt.rm, nxt.rv, nxt.nbt),
+                                     act_dst=None if fuse(self.blocks[b + 1], out) else a0, **c2)
             else:
-                rec_conv(P, "b%d.c2" % b, a1, out, blk.conv2, 0, add_post=resid)
+                rec_conv(P, "b%d.c2" % b, src2, out, blk.conv2, 0, **c2)
             cur, chw = out, ohw
         return cur, chw
 

@@ -110,10 +110,12 @@ class PackedConv:
 def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = None, bias=None, add_pre=None,
               mask_x=None, mask: Optional[Affine] = None, mask_mul_scale=False, add_post=None, tanh_out=False,
               stats_kind=0, stats=None, xh_mean=None, xh_rstd=None, tile=0, act_dst=None,
-              act: Optional[Affine] = None, mask_activated=False, workspace=None, shortcut=None) -> ConvArgs:
+              act: Optional[Affine] = None, mask_activated=False, workspace=None, shortcut=None,
+              pro_act_dst=None) -> ConvArgs:
     """act_dst / act: second output bf16(lrelu(y * act.scale + act.shift)) of the stored value y (the
     next layer's eval-mode BatchNorm + ReLU); dst may then be None.  mask_activated: mask_x is such an
-    activation (kept-test mask_x > 0)."""
+    activation (kept-test mask_x > 0).  pro_act_dst: src-shaped tensor that receives the prologue's result
+    pro(src) (combat_conv_args.pro_act_dst: DMA-staged 3x3 kernel with a per-channel prologue)."""
     a = ConvArgs()
     a.N, a.H, a.W, a.C = src.shape
     _, a.P, a.Q, a.K = (dst if dst is not None else act_dst).shape
@@ -131,6 +133,9 @@ def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = No
     if pro is not None:
         a.pro_scale, a.pro_shift = _p(pro.scale), _p(pro.shift)
         a.pro_group_stride, a.pro_act, a.pro_slope = pro.group_stride, int(pro.act), pro.slope
+    if pro_act_dst is not None:
+        assert pro is not None and tuple(pro_act_dst.shape) == tuple(src.shape)
+        a.pro_act_dst = pro_act_dst.data_ptr()
     a.bias, a.add_pre, a.mask_x, a.add_post = _p(bias), _p(add_pre), _p(mask_x), _p(add_post)
     if mask is not None:
         a.mask_scale, a.mask_shift = _p(mask.scale), _p(mask.shift)
@@ -150,7 +155,7 @@ def conv_args(src, dst, pc: PackedConv, mode: int, *, pro: Optional[Affine] = No
             a.workspace, a.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     # the struct holds raw pointers: keep every tensor alive as long as the struct is
     a._keepalive = (src, dst, pc, pro, bias, add_pre, mask_x, mask, add_post, stats, xh_mean, xh_rstd, act_dst, act,
-                    workspace, shortcut)
+                    workspace, shortcut, pro_act_dst)
     return a
 
 

@@ -122,6 +122,13 @@ typedef struct combat_conv_args {
        tensor; the epilogue (mask, statistics, residuals) then sees the sum, as it did through add_pre. */
     const void *src2, *wpack2;
     int32_t kpad2, rows_pad2;
+    /* second output of the PROLOGUE (may be NULL; forward 3x3 / stride-1 launches with a per-channel prologue on the
+       DMA-staged kernel, which applies the prologue in LDS after the operand has landed): the activated input
+       pro_act_dst[m][c] = bf16(lrelu(src[m][c] * pro_scale[c] + pro_shift[c], pro_slope)), src-shaped -- the tensor
+       the weight gradient of this layer reads, written by the launch that computes it anyway instead of by a
+       normalisation launch of its own in front of it (train-mode relu(bn(x)): preact_resnet.py:32,35).  Launches that
+       cannot honour it return COMBAT_EINVAL (combat_conv_pick_tile says which kernel a launch takes). */
+    void *pro_act_dst;
 } combat_conv_args;
 
 #define COMBAT_STATS_PER_WORKGROUP 4
@@ -242,7 +249,7 @@ int combat_norm_finalize(const float *partials, int32_t groups, int32_t rows_per
                          float *mean, float *rstd, float *scale, float *shift,
                          float *running_mean, float *running_var, float momentum,
                          int64_t *num_batches_tracked, float *scratch, int64_t scratch_bytes, void *stream);
-/* rows_per_group > 128 is reduced in two launches through `scratch`
+/* rows_per_group > 256 is reduced in two launches through `scratch`
  * (>= combat_norm_scratch_bytes(groups, C) bytes); smaller problems ignore it (may be NULL). */
 int64_t combat_norm_scratch_bytes(int32_t groups, int32_t C);
 

@@ -252,6 +252,76 @@ def test_conv3x3_weight_stationary_equals_ring_kernel(ops, n, hw):
     assert lib.combat_conv_pick_tile(ctypes.byref(a)) == (17 if tiles >= 512 else (11 if tiles <= 256 else 10))
 
 
+LDS_PRO_CASES = [
+    # n, hw, c, k, tile: every 3x3 / stride-1 shape of PreActResNet18 (and the generator's) at B = 128, both channel
+    # tiles; then ragged image counts on the maps where a tile holds several images, and other widths
+    (128, 32, 64, 64, 10), (128, 16, 128, 128, 10), (128, 16, 128, 128, 11), (128, 8, 256, 256, 10), (128, 8, 256, 256, 11),
+    (128, 4, 512, 512, 10), (128, 4, 512, 512, 11), (128, 8, 256, 128, 11), (128, 16, 128, 64, 10), (128, 4, 512, 256, 11),
+    (5, 32, 64, 64, 11), (5, 8, 128, 64, 10), (9, 4, 256, 256, 11), (3, 16, 64, 128, 10), (2, 64, 64, 64, 10),
+]
+
+
+@pytest.mark.parametrize("n,hw,c,k,tile", LDS_PRO_CASES)
+def test_conv_lds_prologue_equals_norm_act_then_conv(ops, n, hw, c, k, tile):
+    """the train-mode BatchNorm + ReLU of a convolution's input applied IN LDS by the DMA-staged
+    kernel (combat_conv_args.pro_* + pro_act_dst) against the chain it replaces -- combat_norm_act_fused materialises
+    relu(bn(x)), then the prologue-free convolution on the same tile.  Same tiles, same MFMA order, same epilogue:
+    the raw output, the statistics rows and the activated side tensor must be BIT-identical, with and without the
+    residual / statistics epilogue (the two flavours a train-mode network launches)."""
+    from combat_amd._lib import lib
+    import ctypes
+    st = torch.cuda.current_stream().cuda_stream
+    x = nhwc(torch.randn(n, c, hw, hw, generator=g(900)) * 1.5 + 0.3)
+    res = nhwc(torch.randn(n, k, hw, hw, generator=g(901)))
+    w, pc = make_conv(ops, k, c, 3, 1, 1, 902)
+    gamma = dev(torch.rand(c, generator=g(903)) + 0.5) * dev(torch.where(torch.rand(c, generator=g(904)) < 0.2, -1.0, 1.0))
+    beta = dev(torch.randn(c, generator=g(905)) * 0.3)
+    # ---- the chain: statistics rows of x (as a producing convolution's epilogue leaves them) -> one fused launch
+    m = n * hw * hw
+    parts = m // 32
+    part = torch.zeros(parts, 2, c, device="cuda")
+    ops.check(lib.combat_group_stats(x.data_ptr(), parts, 32, c, part.data_ptr(), st), "group_stats")
+    mean, rstd, scale, shift = (torch.zeros(c, device="cuda") for _ in range(4))
+    scratch = torch.zeros(ops.norm_scratch_bytes(1, c) // 4, device="cuda")
+    act = torch.zeros_like(x)
+    ops.check(lib.combat_norm_act_fused(x.data_ptr(), part.data_ptr(), 1, parts, m, c, 1e-5, 0.0, gamma.data_ptr(), beta.data_ptr(),
+                                        mean.data_ptr(), rstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), None, None, 0.1, None,
+                                        scratch.data_ptr(), scratch.numel() * 4, act.data_ptr(), st), "norm_act_fused")
+    aff = ops.Affine(scale, shift, 0, True, 0.0)
+    for name, kw in (("plain + residual", dict(add_post=res)), ("statistics + residual", dict(add_post=res, stats_kind=1 | 4)),
+                     ("statistics", dict(stats_kind=1))):
+        outs = []
+        for fused in (False, True):
+            o = dict(y=torch.zeros(n, hw, hw, k, dtype=bf16, device="cuda"))
+            if fused:
+                o["side"] = torch.full_like(x, 7.0)
+                a = ops.conv_args(x, o["y"], pc, 0, pro=aff, pro_act_dst=o["side"], tile=tile, **kw)
+            else:
+                o["side"] = act
+                a = ops.conv_args(act, o["y"], pc, 0, tile=tile, **kw)
+            assert lib.combat_conv_pick_tile(ctypes.byref(a)) == tile, (name, fused)
+            if a.stats_kind:
+                rows, rpi = ops.conv_stats_layout(a)
+                o["stats"] = torch.zeros(rows, 2, k, device="cuda")
+                a.stats = o["stats"].data_ptr()
+                o["layout"] = (rows, rpi)
+            ops.conv_launch(a)
+            torch.cuda.synchronize()
+            outs.append(o)
+        for key in outs[0]:
+            if key == "layout":
+                assert outs[0][key] == outs[1][key], name
+            else:
+                assert torch.equal(outs[0][key], outs[1][key]), (name, key, n, hw, c, k, tile)
+    # the prologue without the side tensor, leaky slope, automatic tile: against fp32 torch
+    y = torch.zeros(n, hw, hw, k, dtype=bf16, device="cuda")
+    a = ops.conv_args(x, y, pc, 0, pro=ops.Affine(scale, shift, 0, True, 0.2))
+    assert lib.combat_conv_pick_tile(ctypes.byref(a)) in (10, 11)
+    ops.conv_launch(a)
+    xa = rb(F.leaky_relu(nchw(x) * scale.cpu()[None, :, None, None] + shift.cpu()[None, :, None, None], 0.2))
+    assert rel_l2(nchw(y), F.conv2d(xa, rb(w), padding=1)) < 4e-3
+
+
 @pytest.mark.parametrize("n,hw,c,k,stride,tile,waves", [
     (5, 32, 64, 64, 1, 10, 4), (3, 16, 128, 128, 1, 10, 4), (5, 8, 128, 64, 1, 10, 4), (9, 4, 256, 256, 1, 11, 4),   # ring kernel (ragged N on small maps)
     (3, 32, 64, 64, 1, 14, 8), (7, 8, 128, 64, 1, 14, 8),                   # ... 256-pixel tiles, eight waves
