@@ -473,9 +473,15 @@ def _tile_preference(a) -> None:
 
 
 FUSE_SHORTCUT = os.environ.get("COMBAT_NO_FUSED_SHORTCUT", "0") != "1"
-# train-mode BatchNorm + ReLU applied by the CONSUMING convolution in LDS (PreActEngine._forward_train_body); 0: A/B, the
-# round-3 form (one combat_norm_act_fused launch per BatchNorm)
-FUSED_PROLOGUE = os.environ.get("COMBAT_NO_FUSED_PROLOGUE", "0") != "1"
+# COMBAT_FUSED_PROLOGUE=1: train-mode BatchNorm + ReLU applied by the CONSUMING convolution in LDS
+# (PreActEngine._forward_train_body, conv3x3_dma_pro_kernel) instead of one combat_norm_act_fused launch per BatchNorm.
+# OFF by default: built, bit-identical (tests/test_kernels_gpu.py::test_conv_lds_prologue_equals_norm_act_then_conv) and
+# measured SLOWER -- 3.885 against 3.757 ms/step on one box (profiles/r04_a_*): every channel tile of the consumer
+# repeats the transform (16x on a 512-channel layer with 32-channel tiles), the patch of a 4 x 4 map is three times
+# its pixels, and the 64-channel layers lose the weight-stationary kernel; tools/pro_bench.py has the per-shape table
+# (back to back: +3.8 us on 64 -> 64 @ 32 x 32, +9 on 256 -> 256 @ 8 x 8, +17 on 512 -> 512 @ 4 x 4, against
+# 4-7 us for the stand-alone activation pass).  DESIGN.md section 5, round 4.
+FUSED_PROLOGUE = os.environ.get("COMBAT_FUSED_PROLOGUE", "0") == "1"
 
 
 def fuse_shortcut(dy, dx, pc: PackedConv, dy_sc, pc_sc: PackedConv):

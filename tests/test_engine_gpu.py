@@ -875,6 +875,52 @@ def test_alternated_step_runs_with_sampled_randomness_and_empty_poison(mods):
     assert st2._side is st._side and st._side is not None
 
 
+def test_preact_train_forward_with_lds_prologue_equals_the_chain(mods):
+    """COMBAT_FUSED_PROLOGUE=1 (engine.FUSED_PROLOGUE): PreActResNet18's train forward with relu(bn(.)) applied in LDS
+    by the consuming convolutions (conv3x3_dma_pro_kernel + combat_norm_finalize) against the default chain
+    (combat_norm_act_fused + prologue-free convolution).  At B = 128 both run the same tiles on every layer (the
+    weight-stationary kernel of the chain's 64-channel layers is bit-identical to the ring tile), so every stored
+    tensor of the forward -- raw outputs, activated tensors, statistics, running statistics, loss -- is BIT-identical
+    (both modes recorded with the ring tiles: the persistent kernel groups its statistics rows per workgroup);
+    the backward reads the same tensors (gradient: fp32-atomic noise of a few weight-gradient launches only).  The
+    opt-in path is slower (engine.py) and stays off; this keeps it correct."""
+    engine, nets = mods["engine"], mods["nets"]
+    b = 128
+    res = {}
+    prev = engine.FUSED_PROLOGUE
+    try:
+        for fused in (False, True):
+            engine.FUSED_PROLOGUE = fused
+            net = seeded(nets.PreActResNet18, 0).cuda()
+            eng = net._net_engine()
+            eng.refresh()
+            slot = eng.slot("pro.%d" % fused, b, 32)
+            x, t = bench_batch(0)
+            ops_ = mods["ops"]
+            xd = x.cuda()
+            ops_.image_to_c8(xd, eng.input(slot))
+            eng.head_bufs(slot)["targets"].copy_(t)
+            with engine.short_workgroups():       # (ring tiles in both modes: the persistent kernel groups its statistics rows differently)
+                fwd, bwd = eng.forward_plan(slot, True), eng.backward_train_plan(slot)
+            names = [w for _, _, w in fwd.calls]
+            assert any(w.endswith(".finalize") for w in names) == fused
+            assert sum(w.endswith(".finact") for w in names) == (3 if fused else 16)      # the stride-2 blocks' inputs stay materialised
+            fwd.run()
+            bwd.run()
+            torch.cuda.synchronize()
+            res[fused] = ({k: v.clone() for k, v in slot.bufs.items() if not k.startswith("g.")}, eng.fp.grad.clone(),
+                          {k: v.detach().clone() for k, v in net.state_dict().items() if "running" in k or "num_batches" in k})
+    finally:
+        engine.FUSED_PROLOGUE = prev
+    (ba, ga, ra), (bb, gb, rb_) = res[False], res[True]
+    for k in sorted(ba):
+        if k in bb and ba[k].shape == bb[k].shape and not k.endswith(".part"):       # (row counts differ: one row per persistent workgroup / per tile)
+            assert torch.equal(ba[k], bb[k]), k
+    for k in ra:
+        assert torch.equal(ra[k], rb_[k]), k
+    assert rel_l2(gb, ga) < 1e-5
+
+
 def test_step_keeps_a_dropped_pinned_batch_alive(mods):
     """combat_copy3 reads a pinned host batch through its device mapping, unseen by torch's caching
     host allocator.  A caller that drops its per-batch pin_memory() tensor right after run() (a DataLoader with
