@@ -50,6 +50,7 @@ class WgradArgs(C.Structure):
         ("pro_slope", c_f32), ("split", c_i32),
         ("workspace", c_vp), ("workspace_bytes", c_i64),
         ("defer_reduce", c_i32), ("reserved", c_i32),
+        ("reduce_first", c_vp),
     ]
 
 

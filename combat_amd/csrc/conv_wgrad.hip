@@ -516,8 +516,15 @@ extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
     p.ntaps = a->R * a->S;
     hipStream_t st = as_stream(stream);
     if (a->split >= 0) {   // split < 0 forces the generic kernel (tests)
-        int rc = conv_wgrad3x3_dma_try(a, st);   // prologue-free input: both operands by LDS-DMA
-        if (rc == 1) rc = conv_wgrad3x3_try(a, st);
+        int rc = conv_wgrad3x3_dma_try(a, st);   // prologue-free input: both operands by LDS-DMA (takes reduce_first along)
+        if (rc <= 0) return rc;
+    }
+    if (a->reduce_first) {   // the kernels below have no reduce-first prologue: that launch's reduction as a launch of its own
+        const int rc = combat_conv_wgrad_reduce(a->reduce_first, stream);
+        if (rc != COMBAT_OK) return rc;
+    }
+    if (a->split >= 0) {
+        const int rc = conv_wgrad3x3_try(a, st);
         if (rc <= 0) return rc;
     }
     if (a->split < 0) p.a.split = 0;

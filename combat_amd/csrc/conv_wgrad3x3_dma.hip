@@ -32,6 +32,11 @@ struct W3dParams {
     int tiles_x, tiles_y, ntiles, tiles_k, tiles_c, split, per;
     unsigned x_bytes, dy_bytes;
     float *ws;   // partial-sum slabs [split][tiles_k][tiles_c][9][64][64] or null (atomics)
+    // the partial sums an EARLIER launch left behind (combat_wgrad_args.reduce_first), folded into its dw by this
+    // launch's workgroups before they start on their own patches: see reduce_slabs()
+    const float *red_ws;
+    float *red_dw;
+    int red_base, red_tiles_c, red_split, red_k_real, red_c_real, red_pad;
     unsigned long long *stamps;   // profiling builds only (-DCOMBAT_STAMPS): cycles per phase, per workgroup
 };
 
@@ -68,6 +73,81 @@ __device__ __forceinline__ void wait_vm_lgkm0_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// dw += sum over the pixel ranges' slabs, by the calling workgroup for ITS share of the register quads, without
+// atomics: the quads of the [base][9][1024] partial-tile space (fragment order, as the kernel below stores them) are
+// dealt to the workgroups in contiguous runs; inside a workgroup thread (slab lane sl, quad ql) adds slabs sl, sl + SL,
+// ... in that order, the SL partial sums meet in LDS and are added in lane order by the thread that owns the quad's four
+// dw elements.  Every element is written by exactly one thread and every sum has a fixed order: the weight gradient
+// is bit-reproducible.  NT threads; `scratch`: NT x 64 bytes of LDS.
+// Quad f4 of a tap = [dy fragment i][wave][lane]: rows (i * 2 + (wave & 1)) * 16 + (lane >> 4) * 4 + 0..3 of column
+// (wave >> 1) * 16 + (lane & 15).
+template <int NT>
+__device__ __forceinline__ void reduce_slabs(const float *__restrict__ ws, float *__restrict__ dw, int base, int tiles_c, int split,
+                                             int k_real, int c_real, unsigned char *scratch, int block, int nblocks) {
+    constexpr int U = 4;                                           // quads per thread and pass: 4 x 4 loads in flight
+    const int tid = threadIdx.x;
+    const long e4 = (long)base * 9 * 1024;
+    const long per = (e4 + nblocks - 1) / nblocks;
+    const long q0 = (long)block * per, q1 = q0 + per < e4 ? q0 + per : e4;
+    // slab lanes: as many as still let ONE pass cover the workgroup's quads (passes are serial, each a memory round trip)
+    int SL = 1;
+    while (SL * 2 <= split && SL < 32 && (long)(NT / (SL * 2)) * U >= per) SL *= 2;
+    const int QP = NT / SL, sl = tid / QP, ql = tid - sl * QP;
+    const int nsl = (split - sl + SL - 1) / SL;                     // slabs of this lane: sl, sl + SL, ...
+    f32x4_t *scr = reinterpret_cast<f32x4_t *>(scratch);
+    const size_t sstride = (size_t)base * 9 * 4096;
+    for (long qb = q0; qb < q1; qb += (long)QP * U) {
+        f32x4_t acc[U];
+        long qq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[u] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            qq[u] = qb + (long)u * QP + ql;
+        }
+        for (int i = 0; i < nsl; i += 4) {
+            f32x4_t v[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = qq[u] < q1 && i + j < nsl;
+                    const float *src = ws + (ok ? qq[u] : q0) * 4 + (size_t)(ok ? sl + (i + j) * SL : 0) * sstride;
+                    const f32x4_t x = *reinterpret_cast<const f32x4_t *>(src);
+                    v[u][j] = ok ? x : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        }
+        if (SL > 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) scr[tid * U + u] = acc[u];
+            __syncthreads();
+            if (sl == 0)
+                for (int l = 1; l < SL; ++l)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) acc[u] += scr[(l * QP + ql) * U + u];
+        }
+        if (sl == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long q = qq[u];
+                if (q >= q1) continue;
+                const int f4 = (int)(q & 1023), tap = (int)((q >> 10) % 9), tile = (int)(q / (9 * 1024));
+                const int i = f4 >> 9, wave = (f4 >> 6) & 7, lane = f4 & 63;
+                const int row = (i * 2 + (wave & 1)) * 16 + (lane >> 4) * 4, col = (wave >> 1) * 16 + (lane & 15);
+                const int tile_c = tile % tiles_c, tile_k = tile / tiles_c;
+                const int n = tile_k * 64 + row, c = tile_c * 64 + col;
+                if (c < c_real) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < k_real) dw[((size_t)(n + e) * 9 + tap) * c_real + c] += acc[u][e];
+                }
+            }
+        }
+        if (SL > 1) __syncthreads();
+    }
+}
+
 // HPW = x halo pieces (8 rows each) per wave (compile time: the counted vmcnt waits need the DMA count
 // of a stage), NS = stages in the LDS ring (NS - 1 patches are in flight ahead of the one being consumed)
 // Where a patch's 2 600 cycles go (per-wave in-kernel stamps, 16 patches per workgroup): all eight waves issue their
@@ -85,6 +165,14 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_k = wid & 1, wave_c = wid >> 1;          // 2 x 4 waves over (n, c)
+    // ---- first: this workgroup's share of the PREVIOUS weight gradient's slab reduction (same queue: that launch has
+    // completed).  It used to be a launch of its own behind every weight gradient -- 24 per step, ~11 us each on the
+    // auxiliary queue; here it is ~1/128 of the slabs per workgroup (147 KB, mostly from L2 / the Infinity Cache)
+    // before the first patch is asked for.
+    if (p.red_ws) {
+        reduce_slabs<512>(p.red_ws, p.red_dw, p.red_base, p.red_tiles_c, p.red_split, p.red_k_real, p.red_c_real, smem, blockIdx.x, gridDim.x);
+        __syncthreads();       // (the scratch is the first DMA stage)
+    }
     int bid = blockIdx.x;
     const int tile_c = bid % p.tiles_c; bid /= p.tiles_c;
     const int tile_k = bid % p.tiles_k;
@@ -443,6 +531,14 @@ __global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float *__res
     }
 }
 
+// stand-alone form of reduce_slabs (the last weight gradient of a queue has no successor to ride with; launches
+// without defer_reduce): 256 workgroups of 256 threads
+__global__ __launch_bounds__(256) void wgrad3x3_reduce_det_kernel(const float *__restrict__ ws, float *__restrict__ dw, int base,
+                                                                  int tiles_c, int split, int k_real, int c_real) {
+    __shared__ __attribute__((aligned(16))) unsigned char scratch[256 * 64];
+    reduce_slabs<256>(ws, dw, base, tiles_c, split, k_real, c_real, scratch, blockIdx.x, gridDim.x);
+}
+
 // (the body is a device function: the host pass cannot see the buffer-resource type it uses)
 template <int HPW, int NS>
 __global__ __launch_bounds__(512, 1) void conv_wgrad3x3_dma_kernel(const W3dParams p) { wgrad3x3_dma_body<HPW, NS>(p); }
@@ -540,15 +636,44 @@ bool w3d_plan(const combat_wgrad_args *a, W3dParams &p) {
 
 int launch_reduce(const combat_wgrad_args *a, const W3dParams &p, hipStream_t st) {
     const int base = p.tiles_k * p.tiles_c;
-    // enough workgroups to fill the chip; each group of ranges costs one fp32 atomic per element
-    const long e4 = (long)base * 9 * 1024;
-    int groups = (int)(512 / ((e4 + 255) / 256));
-    if (groups < 1) groups = 1;
-    if (groups > p.split) groups = p.split;
-    COMBAT_LAUNCH(wgrad3x3_reduce_kernel, dim3((unsigned)((e4 + 255) / 256), groups), dim3(256), 0, st, p.ws, a->dw, base,
-                       p.tiles_c, p.split, a->k_real, a->c_real);
+    // Default: the round-3 reduction (ranges dealt to <= 14 groups of workgroups, one fp32 atomic per element and group):
+    // 4-8 us back to back.  COMBAT_WGRAD_DET_REDUCE=1: reduce_slabs() as a launch of its own -- fixed summation order, no
+    // atomics, bit-reproducible -- 9-18 us (tools/wgrad_chain_bench.py): a workgroup owns whole elements, so the slabs
+    // of an element cannot be spread over the chip.
+    static const bool atomics = getenv("COMBAT_WGRAD_DET_REDUCE") == nullptr;
+    if (atomics) {
+        // enough workgroups to fill the chip; each group of ranges costs one fp32 atomic per element
+        const long e4 = (long)base * 9 * 1024;
+        int groups = (int)(512 / ((e4 + 255) / 256));
+        if (groups < 1) groups = 1;
+        if (groups > p.split) groups = p.split;
+        COMBAT_LAUNCH(wgrad3x3_reduce_kernel, dim3((unsigned)((e4 + 255) / 256), groups), dim3(256), 0, st, p.ws, a->dw, base,
+                           p.tiles_c, p.split, a->k_real, a->c_real);
+    } else {
+        COMBAT_LAUNCH(wgrad3x3_reduce_det_kernel, dim3(256), dim3(256), 0, st, (const float *)p.ws, a->dw, base, p.tiles_c, p.split,
+                           a->k_real, a->c_real);
+    }
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
+}
+
+// `prev`: a launch recorded with defer_reduce whose slabs this launch folds into prev->dw first (reduce_first)
+bool fill_reduce_first(const combat_wgrad_args *prev, W3dParams &p) {
+    p.red_ws = nullptr;
+    p.red_dw = nullptr;
+    p.red_base = p.red_tiles_c = p.red_split = p.red_k_real = p.red_c_real = p.red_pad = 0;
+    if (!prev) return true;
+    W3dParams q;
+    if (!w3d_plan(prev, q)) return false;
+    if (!q.ws) return true;                  // (that launch needed no reduction)
+    p.red_ws = q.ws;
+    p.red_dw = prev->dw;
+    p.red_base = q.tiles_k * q.tiles_c;
+    p.red_tiles_c = q.tiles_c;
+    p.red_split = q.split;
+    p.red_k_real = prev->k_real;
+    p.red_c_real = prev->c_real;
+    return true;
 }
 }  // namespace
 
@@ -556,6 +681,7 @@ int launch_reduce(const combat_wgrad_args *a, const W3dParams &p, hipStream_t st
 int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st) {
     W3dParams p;
     if (!w3d_plan(a, p)) return 1;
+    if (!fill_reduce_first(a->reduce_first, p)) return COMBAT_EINVAL;
 #ifdef COMBAT_STAMPS
     p.stamps = g_stamps_wgrad_host;
 #else

@@ -68,6 +68,8 @@ class Plan:
         self._prog = None
         self.after: Dict[int, int] = {}   # call index -> index of an earlier call it waits for (on whatever queue that ran)
         self.pending_reduces: List[Tuple] = []   # (what, WgradArgs, index of its weight-gradient call)
+        self.chain: Dict[int, Tuple] = {}        # auxiliary queue -> (what, WgradArgs) of the launch whose slabs await the next one
+        self.chain_count: Dict[int, int] = {}    # auxiliary queue -> slab-leaving launches so far (alternates the two regions)
 
     def add(self, what: str, cfunc, *args, aux: bool = False, after: Optional[int] = None) -> None:
         """aux: the call's result is only consumed after the plan (weight gradients: by the optimiser /
@@ -88,6 +90,7 @@ class Plan:
         for what, a, ci in self.pending_reduces:
             self.add(what, lib.combat_conv_wgrad_reduce, ctypes.byref(a), after=ci)
         self.pending_reduces = []
+        self.chain = {}      # (reduce-behind: the chains' last launches were in the list above; the next launch starts a new chain)
 
     def next_aux_queue(self) -> int:
         """Queue the next aux call will be given (round-robin over `aux_queues`)."""
@@ -473,6 +476,13 @@ def _tile_preference(a) -> None:
 
 
 FUSE_SHORTCUT = os.environ.get("COMBAT_NO_FUSED_SHORTCUT", "0") != "1"
+# COMBAT_REDUCE_BEHIND=1: a weight gradient's slab reduction rides in the NEXT weight-gradient launch of its queue
+# (rec_wgrad, combat_wgrad_args.reduce_first): 23 of the 24 reduction launches of a step disappear and the 3x3 weight
+# gradients become bit-reproducible (fixed summation order, no atomics).  OFF by default: measured 3.84 against 3.74
+# ms/step -- the 128 workgroups of a weight gradient fold 147 KB of slabs each at a CU's ~30 GB/s before their first
+# patch (+8 us per launch, +18 on the 512-channel layers), the round-3 reduction launch spreads the same bytes over the
+# whole chip in 4-8 us (tools/wgrad_chain_bench.py).
+REDUCE_BEHIND = os.environ.get("COMBAT_REDUCE_BEHIND", "0") == "1"
 # COMBAT_FUSED_PROLOGUE=1: train-mode BatchNorm + ReLU applied by the CONSUMING convolution in LDS
 # (PreActEngine._forward_train_body, conv3x3_dma_pro_kernel) instead of one combat_norm_act_fused launch per BatchNorm.
 # OFF by default: built, bit-identical (tests/test_kernels_gpu.py::test_conv_lds_prologue_equals_norm_act_then_conv) and
@@ -514,10 +524,28 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
         a.pro_scale, a.pro_shift = _p(pro.scale), _p(pro.shift)
         a.pro_group_stride, a.pro_act, a.pro_slope = pro.group_stride, int(pro.act), pro.slope
     a.split = 0
-    ws = _wgrad_workspace(src.device, plan.next_aux_queue() if aux else -1)
+    queue = plan.next_aux_queue() if aux else -1
+    ws = _wgrad_workspace(src.device, queue)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     need = int(lib.combat_conv_wgrad_workspace_bytes(ctypes.byref(a)))
-    if aux and need > 0 and Plan.defer_reduces:
+    prev = plan.chain.get(queue) if aux else None
+    if aux and REDUCE_BEHIND and not Plan.defer_reduces and need > 0:      # (need > 0: the DMA-staged 3x3 kernel, several pixel ranges)
+        # Reduce-behind (round 4): a launch that leaves partial-sum slabs does not reduce them; the NEXT weight gradient
+        # of this queue folds them into this launch's dw before it starts on its own patches
+        # (combat_wgrad_args.reduce_first), and only the last one of a chain gets a reduction launch (Plan.flush_reduces).
+        # Slabs live in one of two private regions per queue, used alternately: the reader of region k % 2 (launch
+        # k + 1) has completed before launch k + 2 writes it.
+        if prev is not None:
+            a.reduce_first = ctypes.addressof(prev[1])
+            plan.pending_reduces = [q for q in plan.pending_reduces if q[1] is not prev[1]]
+            plan.hold(prev[1])
+            plan.chain.pop(queue)
+        k = plan.chain_count.get(queue, 0)
+        plan.chain_count[queue] = k + 1
+        ws = _wgrad_slab_region(src.device, queue, k % 2, need)
+        a.workspace, a.workspace_bytes, a.defer_reduce = ws.data_ptr(), ws.numel(), 1
+        plan.chain[queue] = (what, a)
+    elif aux and need > 0 and Plan.defer_reduces:
         # a launch that leaves partial-sum slabs: its reduction is deferred (Plan.flush_reduces), so the slabs need a
         # region of their own until then -- HBM is 288 GB, a backward plan's ~20 regions of 19 MB are not
         ws = torch.empty(need, dtype=torch.uint8, device=src.device)
@@ -527,6 +555,19 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
     plan.wgrads.append((len(plan.calls) - 1, a))
     if a.defer_reduce:
         plan.pending_reduces.append((what + ".reduce", a, len(plan.calls) - 1))
+
+
+_WGRAD_SLABS: Dict = {}
+
+
+def _wgrad_slab_region(device, queue: int, which: int, need: int) -> torch.Tensor:
+    """One of the two slab regions of a queue's reduce-behind chain (rec_wgrad)."""
+    key = (device, int(queue), int(which))
+    t = _WGRAD_SLABS.get(key)
+    if t is None or t.numel() < need:
+        t = torch.empty(max(need, 24 << 20), dtype=torch.uint8, device=device)
+        _WGRAD_SLABS[key] = t
+    return t
 
 
 def balance_wgrads(plan: Plan, device) -> None:

@@ -206,6 +206,16 @@ typedef struct combat_wgrad_args {
                                     with the workspace untouched in between -- so that a chain of weight gradients is not
                                     a chain of (kernel, reduction) pairs.  Launches that need no reduction ignore it. */
     int32_t reserved;
+    const struct combat_wgrad_args *reduce_first;
+                                 /* NULL, or the arguments of an EARLIER launch (HOST pointer, read at launch time)
+                                    that ran with defer_reduce = 1 on the same stream and has not been reduced yet: this
+                                    launch's workgroups first add that launch's partial sums into ITS dw (each workgroup
+                                    a share, fixed summation order, no atomics), then do their own work -- a chain of
+                                    weight gradients then carries its reductions along instead of alternating with ~10-us
+                                    reduction launches; only the chain's last one needs combat_conv_wgrad_reduce.  The
+                                    two launches need disjoint workspaces.  A launch that cannot take it along (kernels
+                                    other than the DMA-staged 3x3 one) reduces it in a launch of its own first: the
+                                    results are the same either way. */
 } combat_wgrad_args;
 
 int combat_conv_wgrad(const combat_wgrad_args *a, void *stream);

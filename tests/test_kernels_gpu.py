@@ -875,6 +875,92 @@ def test_wgrad3x3_dma_kernel(ops, n, hw, c, k):
         assert rel_l2(dw, ref) < 2e-3, (split, ws)
 
 
+def test_wgrad_reduction_rides_in_the_next_weight_gradient(ops):
+    """combat_wgrad_args.reduce_first (round 4): a chain of weight gradients of different layer shapes, each leaving its
+    partial-sum slabs (defer_reduce) for the NEXT launch to fold into the earlier dw first; only the last gets a
+    reduction launch.  The carried reduction has a fixed summation order and no atomics, so (1) every dw of the chain
+    equals the same layer launched alone with its own reduction launch up to summation order, (2) a second chain run
+    reproduces the first BIT for bit, (3) a launch that cannot take its predecessor along (generic kernel) reduces it
+    first.  (Opt-in in the engines -- COMBAT_REDUCE_BEHIND=1 -- because it measured slower: engine.py.)"""
+    import ctypes
+    from combat_amd._lib import WgradArgs, lib
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = [(16, 32, 64, 64), (16, 16, 128, 128), (24, 8, 256, 128), (64, 4, 512, 256), (16, 32, 64, 64)]
+    layers = []
+    for i, (n, hw, c, k) in enumerate(shapes):
+        x = nhwc(torch.randn(n, c, hw, hw, generator=g(300 + i)))
+        dy = nhwc(torch.randn(n, k, hw, hw, generator=g(320 + i)))
+        w, pc = make_conv(ops, k, c, 3, 1, 1, 340 + i)
+        layers.append((x, dy, pc, (k, 9, c), (x.float().cpu(), dy.float().cpu())))
+
+    def args_of(x, dy, pc, dw, ws=None, defer=0, first=None):
+        a = WgradArgs()
+        a.N, a.H, a.W, a.C = x.shape
+        _, a.P, a.Q, a.K = dy.shape
+        a.R = a.S = 3
+        a.stride, a.pad = 1, 1
+        a.src, a.dy, a.dw, a.k_real, a.c_real = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), pc.K, pc.c_real
+        if ws is not None:
+            a.workspace, a.workspace_bytes, a.defer_reduce = ws.data_ptr(), ws.numel(), defer
+        if first is not None:
+            a.reduce_first = ctypes.addressof(first)
+        return a
+
+    # alone: slabs + the stand-alone (deterministic) reduction launch
+    alone = []
+    for x, dy, pc, shp, _ in layers:
+        dw = torch.zeros(shp, device="cuda")
+        probe = args_of(x, dy, pc, dw)
+        need = int(lib.combat_conv_wgrad_workspace_bytes(ctypes.byref(probe)))
+        assert need > 0
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        ops.check(lib.combat_conv_wgrad(ctypes.byref(args_of(x, dy, pc, dw, ws)), st), "wgrad alone")
+        alone.append(dw)
+    torch.cuda.synchronize()
+    for (x, dy, pc, shp, (xf, dyf)), dw in zip(layers, alone):
+        n, hw, _, c = x.shape
+        ref = torch.nn.grad.conv2d_weight(xf.permute(0, 3, 1, 2), (shp[0], c, 3, 3), dyf.permute(0, 3, 1, 2), padding=1)
+        assert rel_l2(dw, ref.permute(0, 2, 3, 1).reshape(shp)) < 2e-3
+
+    def chain():
+        regions = [torch.empty(24 << 20, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        dws, prev, keep = [], None, []
+        for i, (x, dy, pc, shp, _) in enumerate(layers):
+            dw = torch.zeros(shp, device="cuda")
+            a = args_of(x, dy, pc, dw, regions[i % 2], defer=1, first=prev)
+            ops.check(lib.combat_conv_wgrad(ctypes.byref(a), st), "wgrad chain %d" % i)
+            dws.append(dw)
+            keep.append(a)
+            prev = a
+        ops.check(lib.combat_conv_wgrad_reduce(ctypes.byref(prev), st), "last reduce")
+        torch.cuda.synchronize()
+        return dws
+
+    first, second = chain(), chain()
+    for i in range(len(layers)):
+        assert rel_l2(first[i], alone[i]) < 1e-6, i          # (the stand-alone reduction adds the ranges in another order)
+        assert torch.equal(first[i], second[i]), i            # fixed order, no atomics: bit-reproducible
+    # a stride-2 launch (generic kernel) behind a slab-leaving one: the predecessor is reduced by a launch of its own
+    x, dy, pc, shp, _ = layers[0]
+    ws = torch.empty(24 << 20, dtype=torch.uint8, device="cuda")
+    dw0 = torch.zeros(shp, device="cuda")
+    a0 = args_of(x, dy, pc, dw0, ws, defer=1)
+    ops.check(lib.combat_conv_wgrad(ctypes.byref(a0), st), "wgrad")
+    w2, pc2 = make_conv(ops, 128, 64, 3, 2, 1, 399)
+    dy2 = nhwc(torch.randn(16, 128, 16, 16, generator=g(398)))
+    dw2 = torch.zeros(128, 9, 64, device="cuda")
+    a2 = WgradArgs()
+    a2.N, a2.H, a2.W, a2.C = x.shape
+    _, a2.P, a2.Q, a2.K = dy2.shape
+    a2.R = a2.S = 3
+    a2.stride, a2.pad = 2, 1
+    a2.src, a2.dy, a2.dw, a2.k_real, a2.c_real = x.data_ptr(), dy2.data_ptr(), dw2.data_ptr(), 128, 64
+    a2.reduce_first = ctypes.addressof(a0)
+    ops.check(lib.combat_conv_wgrad(ctypes.byref(a2), st), "wgrad stride 2")
+    torch.cuda.synchronize()
+    assert rel_l2(dw0, alone[0]) < 1e-6
+
+
 # ---- the benchmarked shape: every convolution of PreActResNet18 (classifier_models/preact_resnet.py:21,23,27-29,77)
 # and of the UnetGenerator (networks/models.py:275-314) at the metric's per-GPU batch N = 128.  At this size the
 # dispatcher takes branches the small cases above never reach (DMA-tile thresholds on the workgroup count,
