@@ -259,6 +259,34 @@ __device__ __forceinline__ void fused_combine(double (&s1)[8], double (&s2)[8], 
     __syncthreads();
 }
 
+// rows pl, pl + 32, ... of a group's partial-sum array ([rows][2][C], `part` at the group's row 0, this thread's eight
+// channels) added in fp64, FOUR rows' loads (eight 32-byte loads) in flight: as a plain loop every row waited out its own
+// L2 round trip -- eight in a row for the 256 rows a batch-statistics layer leaves.  Ascending row order as before.
+// Called BEFORE the tensor prefetch of the fused kernels (round 3 tried it behind the prefetch: the registers of both
+// at once cost a wave per SIMD and the step 1 %).
+__device__ __forceinline__ void fused_reduce_rows(const float *__restrict__ part, int C, int rpg, int pl, double (&s1)[8], double (&s2)[8]) {
+    for (int r = pl; r < rpg; r += 128) {
+        float u[4][8], v[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rr = r + 32 * q < rpg ? r + 32 * q : r;
+            const float *p = part + ((long)rr * 2) * C;
+            load8f(p, u[q]);
+            load8f(p + C, v[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (r + 32 * q < rpg) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    s1[e] += (double)u[q][e];
+                    s2[e] += (double)v[q][e];
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void fused_channel_sums(double (*sh)[8][16], int ch, double &t1, double &t2) {
     const int co = ch >> 3, e = ch & 7;
     t1 = sh[0][co][e] + sh[1][co][e] + sh[2][co][e] + sh[3][co][e];
@@ -302,24 +330,14 @@ __global__ __launch_bounds__(256) void norm_act_fused_kernel(const FusedFwdArgs 
             if (a.add) la[q] = *reinterpret_cast<const u32x4_t *>(a.add + off);
         }
     };
-    if (live && i0 + pl < i1) load_pass(i0 + pl);
     double s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.0;
+    if (live && a.part) fused_reduce_rows(a.part + ((long)g * a.rpg * 2) * a.C + c, a.C, a.rpg, pl, s1, s2);
+    __builtin_amdgcn_sched_barrier(0);      // (the row loads' registers are dead before the prefetch's are allocated)
+    if (live && i0 + pl < i1) load_pass(i0 + pl);
     if (live) {
-        if (a.part) {
-            for (int r = pl; r < a.rpg; r += 32) {
-                const float *p = a.part + (((long)g * a.rpg + r) * 2) * a.C + c;
-                float u[8], v[8];
-                load8f(p, u);
-                load8f(p + a.C, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1[e] += (double)u[e];
-                    s2[e] += (double)v[e];
-                }
-            }
-        } else {
+        if (!a.part) {
             float f1[8], f2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) f1[e] = f2[e] = 0.f;
@@ -447,7 +465,6 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const FusedBwdArgs 
             if (a.add) la[q] = *reinterpret_cast<const u32x4_t *>(a.add + off);
         }
     };
-    if (live && i0 + pl < i1) load_pass(i0 + pl);
     double s1[8], s2[8];
     float mu[8], rs[8];
 #pragma unroll
@@ -456,22 +473,13 @@ __global__ __launch_bounds__(256) void norm_bwd_fused_kernel(const FusedBwdArgs 
         mu[e] = 0.f;
         rs[e] = 1.f;
     }
+    if (live && a.part) fused_reduce_rows(a.part + ((long)g * a.rpg * 2) * a.C + c, a.C, a.rpg, pl, s1, s2);
+    __builtin_amdgcn_sched_barrier(0);      // (the row loads' registers are dead before the prefetch's are allocated)
+    if (live && i0 + pl < i1) load_pass(i0 + pl);
     if (live) {
         load8f(a.mean + (long)g * a.C + c, mu);
         load8f(a.rstd + (long)g * a.C + c, rs);
-        if (a.part) {
-            for (int r = pl; r < a.rpg; r += 32) {
-                const float *p = a.part + (((long)g * a.rpg + r) * 2) * a.C + c;
-                float u[8], v[8];
-                load8f(p, u);
-                load8f(p + a.C, v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    s1[e] += (double)u[e];
-                    s2[e] += (double)v[e];
-                }
-            }
-        } else {
+        if (!a.part) {
             float f1[8], f2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) f1[e] = f2[e] = 0.f;
