@@ -136,6 +136,10 @@ def low_priority_stream(dev) -> torch.cuda.Stream:
 
 
 SIDE_SHORT_WORKGROUPS = os.environ.get("COMBAT_SIDE_WS", "0") != "1"   # (COMBAT_SIDE_WS=1: A/B, the persistent kernel on the second stream too)
+# COMBAT_MERGE_C_EVAL=1 (A/B): netC's two eval-mode forwards of Phase G (train_generator.py:227-228) as ONE 2n-image
+# pass on the critical queue -- [aug(inputs) ; aug(inputs_bd)], backward on the second half -- as the clean model's
+# already are, instead of the metric-only half on the second stream.  Fewer, fatter launches against a longer critical chain.
+MERGE_C_EVAL = os.environ.get("COMBAT_MERGE_C_EVAL", "0") == "1"
 FORCE_ALLREDUCE = os.environ.get("COMBAT_FORCE_ALLREDUCE", "0") == "1"   # issue the bucketed all-reduces even at world size 1
 #                                                                          (tests: RCCL's streams beside the step's on ONE GPU)
 
@@ -250,26 +254,35 @@ class AlternatedStep:
         # through a view slot.  netC (:227+228): the differentiated forward is on the critical path and runs
         # alone; the accuracy-only forward on the clean images goes to the second stream.
         self.sC_train = eC.slot("C.train", n, hw)
-        self.sC_eval = eC.slot("C.evalbd", n, hw)      # netC on the triggered images: on the critical path, so on its own
-        self.sC_met = eC.slot("C.metric", n, hw)       # netC on the clean images (accuracy only): second stream
+        self.merge_c = MERGE_C_EVAL and type(self) is AlternatedStep
+        if self.merge_c:
+            self.sC_eval = eC.slot("C.eval2", 2 * n, hw)   # [metric half ; loss half]
+            self.sC_met = self.sC_eval
+        else:
+            self.sC_eval = eC.slot("C.evalbd", n, hw)      # netC on the triggered images: on the critical path, so on its own
+            self.sC_met = eC.slot("C.metric", n, hw)       # netC on the clean images (accuracy only): second stream
         self.sK_eval = eK.slot("K.eval2", 2 * n, hw)
         self.sG = self._gen_slot(n)
         self.sF = self.eF.slot("F", n, hw) if self.eF is not None else None
         # the heads read their labels straight out of the step table (bound before the plans marshal pointers)
         lab = self.d_targets
-        self.sC_train.bufs["targets"], self.sC_eval.bufs["targets"], self.sC_met.bufs["targets"] = lab[2], lab[1], lab[0]
+        if self.merge_c:
+            self.sC_train.bufs["targets"], self.sC_eval.bufs["targets"] = lab[2], lab[0:2].view(-1)
+        else:
+            self.sC_train.bufs["targets"], self.sC_eval.bufs["targets"], self.sC_met.bufs["targets"] = lab[2], lab[1], lab[0]
         self.sK_eval.bufs["targets"], self.sK_eval.bufs["targets2"] = lab[3:5].view(-1), lab[5:7].view(-1)
         w_cm = float(self.opt.clean_model_weight)
         self.pl = dict(
             C_train_f=eC.forward_plan(self.sC_train, True), C_train_b=eC.backward_train_plan(self.sC_train),
-            C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False),
+            C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False, split_head=self.merge_c),
         )
         self.pl.update(self._gen_plans())
-        self.sC_bd = self.sC_eval
+        self.sC_bd = self.sC_eval.half_view(n, n, eC.FWD_SHARED) if self.merge_c else self.sC_eval
         self.pl["C_bd_b"] = eC.backward_eval_plan(self.sC_bd, 1.0)
         # the second stream's passes run beside the critical queue: one tile per workgroup (engine.short_workgroups)
         with (short_workgroups() if SIDE_SHORT_WORKGROUPS else contextlib.nullcontext()):
-            self.pl["C_met_f"] = eC.forward_plan(self.sC_met, False, 1.0, False)
+            if not self.merge_c:
+                self.pl["C_met_f"] = eC.forward_plan(self.sC_met, False, 1.0, False)
             self.pl["K_eval_f"] = eK.forward_plan(self.sK_eval, False, w_cm, True, split_head=True)
             self.sK_bd = self.sK_eval.half_view(n, n, eK.FWD_SHARED)
             self.pl["K_bd_b"] = eK.backward_eval_plan(self.sK_bd, w_cm)
@@ -434,8 +447,12 @@ class AlternatedStep:
 
         # ================= Phase G (train_generator.py:216-255; generator forward and clean-model chain: above) =====
         torch.cuda.current_stream().wait_event(ev_bd)
-        ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, xC.data_ptr(), None, st), "augment 3")
-        pl["C_eval_f"].run(prof)               # :228, :231
+        if self.merge_c:
+            ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, xC.data_ptr(), None, st), "augment 2")
+            ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, xC[n:].data_ptr(), None, st), "augment 3")
+        else:
+            ops.check(lib.combat_augment_fwd(bd_ptr, None, aug_ptr[3], n, hw, xC.data_ptr(), None, st), "augment 3")
+        pl["C_eval_f"].run(prof)               # :228, :231 (merged: + :227)
         # ---- everything that is only logged (:227 accuracy of the updated netC on the clean images, :245-247
         # detector, :234-243 L2 / gradient-L2 terms) is forked to the second stream HERE: underneath the surrogate's
         # input-gradient pass and the generator backward.  Measured on one box (ms/step): forked after the
@@ -448,9 +465,10 @@ class AlternatedStep:
         with torch.cuda.stream(side):
             side.wait_event(ev_late)
             s2 = side.cuda_stream
-            ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, eC.input(self.sC_met).data_ptr(), None, s2),
-                      "augment 2")
-            pl["C_met_f"].run(prof)
+            if not self.merge_c:
+                ops.check(lib.combat_augment_fwd(x_ptr, None, aug_ptr[2], n, hw, eC.input(self.sC_met).data_ptr(), None, s2),
+                          "augment 2")
+                pl["C_met_f"].run(prof)
             if eF is not None:
                 ops.check(lib.combat_dct_u8(bd_ptr, self.D.data_ptr(), n, hw, eF.input(self.sF).data_ptr(), s2), "dct")
                 pl["F_f"].run(prof)
@@ -537,7 +555,7 @@ class AlternatedStep:
             out["loss_c_sum"] += float(cC["loss"])
             out["loss_ce_sum"] += float(cE["loss"])
             out["clean_model_loss_sum"] += float(kE["loss"]) / w_cm
-            out["clean_correct"] += int(self.eC.head_bufs(sCm)["correct"][0])
+            out["clean_correct"] += int(sCm.bufs["correct0"][0]) if "correct0" in sCm.bufs else int(self.eC.head_bufs(sCm)["correct"][0])
             out["bd_correct"] += int(cE["correct"][0])
             out["clean_model_correct"] += int(sKe.bufs["correct0"][0])
             out["clean_model_bd_ba"] += int(kE["correct"][0])
