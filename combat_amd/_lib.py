@@ -115,6 +115,9 @@ SIGNATURES = {
                                   c_vp, c_vp, c_vp]),
     "combat_head_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
                                   c_vp]),
+    "combat_head_fwd_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                      c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "combat_head_bwd_weights": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "combat_sgd_nesterov": (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "combat_image_to_c8": (C.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "combat_nhwc_to_nchw_f32": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

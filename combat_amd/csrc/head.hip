@@ -75,6 +75,81 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
     }
 }
 
+// head_fwd_kernel + head_bwd_feat_kernel in ONE launch (round 4): the forward has everything the feature gradient needs
+// (logits in LDS, the label), and on the critical queue the pair was two dependent ~10-us launches with a 6.5-us bubble
+// between them -- the end of every classifier forward pass whose loss is differentiated.  Same arithmetic, same order.
+__global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const HeadFwdArgs a, float *__restrict__ dlogits, __bf16 *__restrict__ d_feat) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // pooled features [in], then their gradient
+    __shared__ float lg[kMaxClasses], dl[kMaxClasses];
+    const int tid = threadIdx.x, img = blockIdx.x;
+    const int ph = a.hw / 4, in = a.C * ph * ph;
+    for (int i = tid; i < in; i += 256) {
+        const int c = i / (ph * ph), r = i - c * ph * ph;
+        const int py = r / ph, px = r - py * ph;
+        float s = 0.f;
+        for (int dy = 0; dy < 4; ++dy)
+            for (int dx = 0; dx < 4; ++dx)
+                s += (float)a.feat[(((long)img * a.hw + py * 4 + dy) * a.hw + px * 4 + dx) * a.C + c];
+        s *= (1.f / 16.f);
+        sm[i] = s;
+        if (a.pooled) a.pooled[(long)img * in + i] = s;
+    }
+    __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int j = wv; j < a.classes; j += 4) {
+            float s = 0.f;
+            for (int i = lane; i < in; i += 64) s = fmaf(sm[i], a.W[(long)j * in + i], s);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) {
+                lg[j] = s + a.b[j];
+                a.logits[(long)img * a.classes + j] = lg[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float mx = lg[0];
+        int am = 0;
+        for (int j = 1; j < a.classes; ++j)
+            if (lg[j] > mx) {
+                mx = lg[j];
+                am = j;
+            }
+        float se = 0.f;
+        for (int j = 0; j < a.classes; ++j) se += expf(lg[j] - mx);
+        const int t = (int)a.targets[img];
+        const float li = logf(se) + mx - lg[t];
+        if (a.loss_sum) atomicAdd(a.loss_sum, a.loss_weight * li / (float)a.n);
+        if (a.correct && am == t) atomicAdd(a.correct, 1);
+        if (a.targets2 && a.correct2 && am == (int)a.targets2[img]) atomicAdd(a.correct2, 1);
+        for (int j = 0; j < a.classes; ++j) {       // (head_bwd_feat_kernel's expression, from the same logits)
+            const float v = a.loss_weight / (float)a.n * (expf(lg[j] - mx) / se - (j == t ? 1.f : 0.f));
+            dl[j] = v;
+            dlogits[(long)img * a.classes + j] = v;
+        }
+    }
+    __syncthreads();
+    if (!d_feat) return;
+    for (int i = tid; i < in; i += 256) {
+        float s = 0.f;
+        for (int j = 0; j < a.classes; ++j) s = fmaf(dl[j], a.W[(long)j * in + i], s);
+        sm[i] = s * (1.f / 16.f);
+    }
+    __syncthreads();
+    const int nch = a.C >> 3, hw = a.hw;
+    for (int t = tid; t < hw * hw * nch; t += 256) {
+        const int ch = (t % nch) * 8, px = t / nch;
+        const int y = px / hw, x = px - y * hw;
+        const int py = y >> 2, pxx = x >> 2;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = sm[((ch + e) * ph + py) * ph + pxx];
+        *reinterpret_cast<uint4 *>(d_feat + (((long)img * hw + y) * hw + x) * a.C + ch) = pack8(o);
+    }
+}
+
 // dlogits[s][j] = w/n * (softmax - onehot); d_feat = dlogits W / 16 broadcast over each 4x4 window
 __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float *__restrict__ logits,
                                                             const int64_t *__restrict__ targets, float loss_weight,
@@ -193,5 +268,41 @@ extern "C" int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32
                            classes, dW, db);
         CB_LAUNCH_CHECK();
     }
+    return COMBAT_OK;
+}
+
+extern "C" int combat_head_fwd_bwd(const void *feat, int32_t n, int32_t hw, int32_t C, const float *W, const float *b,
+                                   int32_t classes, const int64_t *targets, float loss_weight, float *pooled,
+                                   float *logits, float *loss_sum, int32_t *correct, const int64_t *targets2,
+                                   int32_t *correct2, float *dlogits, void *d_feat, void *stream) {
+    COMBAT_PLAN_HOOK(combat_head_fwd_bwd, feat, n, hw, C, W, b, classes, targets, loss_weight, pooled, logits, loss_sum, correct, targets2, correct2, dlogits, d_feat);
+    if (!feat || !W || !b || !logits || !targets || !dlogits || n <= 0 || hw < 4 || (hw & 3) || C <= 0 || (C & 7)) return COMBAT_EINVAL;
+    if (classes <= 0 || classes > kMaxClasses) return COMBAT_EINVAL;
+    const int in = C * (hw / 4) * (hw / 4);
+    const int bytes = in * 4;
+    if (bytes > 150 * 1024) return COMBAT_EINVAL;
+    HeadFwdArgs a{reinterpret_cast<const __bf16 *>(feat), hw, C, classes, W, b, targets, targets2, loss_weight, n,
+                  pooled, logits, loss_sum, correct, correct2};
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_fwd_bwd_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return COMBAT_ELAUNCH;
+        attr = true;
+    }
+    COMBAT_LAUNCH(head_fwd_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), a, dlogits, reinterpret_cast<__bf16 *>(d_feat));
+    CB_LAUNCH_CHECK();
+    return COMBAT_OK;
+}
+
+extern "C" int combat_head_bwd_weights(const float *dlogits, const float *pooled, int32_t n, int32_t hw, int32_t C,
+                                       int32_t classes, float *dW, float *db, void *stream) {
+    COMBAT_PLAN_HOOK(combat_head_bwd_weights, dlogits, pooled, n, hw, C, classes, dW, db);
+    if (!dlogits || !pooled || !dW || !db || n <= 0 || hw < 4 || (hw & 3) || C <= 0 || classes <= 0 || classes > kMaxClasses)
+        return COMBAT_EINVAL;
+    const int in = C * (hw / 4) * (hw / 4);
+    COMBAT_LAUNCH(head_bwd_w_kernel, dim3((in + 255) / 256, classes, 8), dim3(256), 0, as_stream(stream), dlogits, pooled, n, in,
+                       classes, dW, db);
+    CB_LAUNCH_CHECK();
     return COMBAT_OK;
 }

@@ -931,11 +931,13 @@ class PreActEngine(NetEngine):
         "b%d.%s" % (b, s) for b in range(8) for s in ("y1", "out", "sc", "a1", "act")) + ("stem.act",)
 
     def forward_plan(self, slot: Slot, train: bool, loss_weight: float = 1.0, with_targets2: bool = False,
-                     split_head: bool = False) -> Plan:
+                     split_head: bool = False, head_bwd: bool = False) -> Plan:
         """split_head (eval only): the batch is two independent halves [metric-only images ; images whose
         loss is differentiated]; the head runs once per half with separate loss / counter cells
-        (first half -> correct[0] of slot 'loss0/correct0' cells, second half -> the usual ones)."""
-        key = "fwd.%s.%g.%d.%d" % ("train" if train else "eval", loss_weight, with_targets2, split_head)
+        (first half -> correct[0] of slot 'loss0/correct0' cells, second half -> the usual ones).
+        head_bwd: the head launch also produces dlogits and the gradient w.r.t. the feature map ('g.feat':
+        combat_head_fwd_bwd), for a pass whose backward plan (built with head_done=True) follows at once."""
+        key = "fwd.%s.%g.%d.%d%s" % ("train" if train else "eval", loss_weight, with_targets2, split_head, ".hb" if head_bwd else "")
         if key in slot.plans:
             return slot.plans[key]
         P = Plan("preact." + key)
@@ -947,7 +949,16 @@ class PreActEngine(NetEngine):
             cur, chw = self._forward_train_body(P, slot, x)
         h = self.head_bufs(slot)
         P.hold(h)
-        if not split_head:
+        if head_bwd:
+            assert not split_head and type(self) is PreActEngine
+            d_feat = slot.buf("g.feat", cur.shape)
+            P.hold(d_feat)
+            P.add("head+bwd", lib.combat_head_fwd_bwd, cur.data_ptr(), n, chw, cur.shape[-1], self.lin_w.data_ptr(),
+                  self.lin_b.data_ptr(), self.classes, h["targets"].data_ptr(), loss_weight, h["pooled"].data_ptr(),
+                  h["logits"].data_ptr(), h["loss"].data_ptr(), h["correct"].data_ptr(),
+                  h["targets2"].data_ptr() if with_targets2 else None,
+                  h["correct"][1:].data_ptr() if with_targets2 else None, h["dlogits"].data_ptr(), d_feat.data_ptr())
+        elif not split_head:
             P.add("head", lib.combat_head_fwd, cur.data_ptr(), n, chw, cur.shape[-1], self.lin_w.data_ptr(),
                   self.lin_b.data_ptr(), self.classes, h["targets"].data_ptr(), loss_weight, h["pooled"].data_ptr(),
                   h["logits"].data_ptr(), h["loss"].data_ptr(), h["correct"].data_ptr(),
@@ -1074,10 +1085,12 @@ class PreActEngine(NetEngine):
         xin = slot.bufs["stem"] if b == 0 else slot.bufs["b%d.out" % (b - 1)]
         return xin, slot.bufs["b%d.y1" % b], slot.bufs["b%d.out" % b]
 
-    def backward_train_plan(self, slot: Slot, loss_weight: float = 1.0) -> Plan:
+    def backward_train_plan(self, slot: Slot, loss_weight: float = 1.0, head_done: bool = False) -> Plan:
         """Backward of a train-mode forward: all parameter gradients (into fp.grad, which the plan
-        zeroes first); no input gradient (Phase C never needs it, train_generator.py:220)."""
-        key = "bwd.train.%g" % loss_weight
+        zeroes first); no input gradient (Phase C never needs it, train_generator.py:220).
+        head_done: the forward plan was built with head_bwd=True -- dlogits and 'g.feat' exist; the linear layer's
+        weight gradient is then an auxiliary-queue launch behind the first input-gradient launch."""
+        key = "bwd.train.%g%s" % (loss_weight, ".hd" if head_done else "")
         if key in slot.plans:
             return slot.plans[key]
         P = Plan("preact." + key)
@@ -1087,21 +1100,31 @@ class PreActEngine(NetEngine):
         P.add("zero_grad", _zero_grad_call, fp)
         feat = slot.bufs["b%d.out" % (len(self.blocks) - 1)]
         d_out = slot.buf("g.feat", feat.shape)
-        P.add("head_bwd", lib.combat_head_bwd, h["pooled"].data_ptr(), n, slot.feat_hw, feat.shape[-1],
-              self.lin_w.data_ptr(), self.classes, h["logits"].data_ptr(), h["targets"].data_ptr(), loss_weight,
-              h["dlogits"].data_ptr(), d_out.data_ptr(), fp.grad_phys("linear.weight").data_ptr(),
-              fp.grad_phys("linear.bias").data_ptr())
+        if not head_done:
+            P.add("head_bwd", lib.combat_head_bwd, h["pooled"].data_ptr(), n, slot.feat_hw, feat.shape[-1],
+                  self.lin_w.data_ptr(), self.classes, h["logits"].data_ptr(), h["targets"].data_ptr(), loss_weight,
+                  h["dlogits"].data_ptr(), d_out.data_ptr(), fp.grad_phys("linear.weight").data_ptr(),
+                  fp.grad_phys("linear.bias").data_ptr())
+        head_w_pending = head_done
         for b in reversed(range(len(self.blocks))):
             blk = self.blocks[b]
             xin, y1, _ = self._block_io(slot, b)
             st1, st2 = slot.norm[blk.bn1.prefix], slot.norm[blk.bn2.prefix]
             a0, a1 = slot.bufs["b%d.a0" % b], slot.bufs["b%d.a1t" % b]   # relu(bn1(xin)), relu(bn2(y1)) of the forward
             pre = blk.prefix
-            rec_wgrad(P, "b%d.c2.wgrad" % b, a1, d_out, blk.conv2, fp.grad_phys(pre + "conv2.weight"))
+            if not head_w_pending:
+                rec_wgrad(P, "b%d.c2.wgrad" % b, a1, d_out, blk.conv2, fp.grad_phys(pre + "conv2.weight"))
             dz2 = slot.buf("g.b%d.dz2" % b, y1.shape)
             self._dgrad_norm(P, slot, "g." + blk.bn2.prefix, d_out, dz2, blk.conv2, y1, st2, group_stride=0,
                              slope=0.0, gamma=blk.bn2.gamma, dgamma=fp.grad_phys(pre + "bn2.weight"),
                              dbeta=fp.grad_phys(pre + "bn2.bias"))
+            if head_w_pending:    # (auxiliary calls behind the plan's first kernel launch: it carries their hand-off event)
+                head_w_pending = False
+                P.hold(h)
+                P.add("head_bwd.w", lib.combat_head_bwd_weights, h["dlogits"].data_ptr(), h["pooled"].data_ptr(), n, slot.feat_hw,
+                      feat.shape[-1], self.classes, fp.grad_phys("linear.weight").data_ptr(), fp.grad_phys("linear.bias").data_ptr(),
+                      aux=True)
+                rec_wgrad(P, "b%d.c2.wgrad" % b, a1, d_out, blk.conv2, fp.grad_phys(pre + "conv2.weight"))
             dy1 = slot.buf("g.b%d.dy1" % b, y1.shape)
             self._bwd_apply(P, slot, "g." + blk.bn2.prefix, dz2, y1, dy1, st2)
             tsc, fused = None, None
@@ -1128,11 +1151,11 @@ class PreActEngine(NetEngine):
         slot.plans[key] = P
         return P
 
-    def backward_eval_plan(self, slot: Slot, loss_weight: float) -> Plan:
+    def backward_eval_plan(self, slot: Slot, loss_weight: float, head_done: bool = False) -> Plan:
         """Backward of an eval-mode forward w.r.t. the input image only (Phase G: the classifier
         and clean-model weight gradients are never consumed, train_generator.py:179,254).
-        Result: slot buffer 'g.img' (bf16 NHWC c8, channels 0..2)."""
-        key = "bwd.eval.%g" % loss_weight
+        Result: slot buffer 'g.img' (bf16 NHWC c8, channels 0..2).  head_done: as backward_train_plan."""
+        key = "bwd.eval.%g%s" % (loss_weight, ".hd" if head_done else "")
         if key in slot.plans:
             return slot.plans[key]
         P = Plan("preact." + key)
@@ -1140,9 +1163,10 @@ class PreActEngine(NetEngine):
         h = self.head_bufs(slot)
         feat = slot.bufs["b%d.out" % (len(self.blocks) - 1)]
         d_out = slot.buf("g.feat", feat.shape)
-        P.add("head_bwd", lib.combat_head_bwd, None, n, slot.feat_hw, feat.shape[-1], self.lin_w.data_ptr(),
-              self.classes, h["logits"].data_ptr(), h["targets"].data_ptr(), loss_weight, h["dlogits"].data_ptr(),
-              d_out.data_ptr(), None, None)
+        if not head_done:
+            P.add("head_bwd", lib.combat_head_bwd, None, n, slot.feat_hw, feat.shape[-1], self.lin_w.data_ptr(),
+                  self.classes, h["logits"].data_ptr(), h["targets"].data_ptr(), loss_weight, h["dlogits"].data_ptr(),
+                  d_out.data_ptr(), None, None)
         for b in reversed(range(len(self.blocks))):
             blk = self.blocks[b]
             # activated tensors of the eval forward: the ReLU mask is (act > 0), the BatchNorm scale multiplies

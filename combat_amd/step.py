@@ -140,6 +140,11 @@ SIDE_SHORT_WORKGROUPS = os.environ.get("COMBAT_SIDE_WS", "0") != "1"   # (COMBAT
 # pass on the critical queue -- [aug(inputs) ; aug(inputs_bd)], backward on the second half -- as the clean model's
 # already are, instead of the metric-only half on the second stream.  Fewer, fatter launches against a longer critical chain.
 MERGE_C_EVAL = os.environ.get("COMBAT_MERGE_C_EVAL", "0") == "1"
+# COMBAT_FUSED_HEAD=1: one head launch per differentiated pass (combat_head_fwd_bwd) and the linear layer's weight gradient
+# beside the input-gradient chain.  OFF by default: two dependent launches and a 6.5-us bubble fewer on the critical queue
+# per pass, and the step did not move (3.765 / 3.762 against 3.735 / 3.742 ms on one box, 3.868 against 3.848 on another):
+# the step is bound by the CU-time of its heavy launches, not by the length of the critical queue's chain.
+FUSED_HEAD = os.environ.get("COMBAT_FUSED_HEAD", "0") == "1"
 FORCE_ALLREDUCE = os.environ.get("COMBAT_FORCE_ALLREDUCE", "0") == "1"   # issue the bucketed all-reduces even at world size 1
 #                                                                          (tests: RCCL's streams beside the step's on ONE GPU)
 
@@ -272,13 +277,16 @@ class AlternatedStep:
             self.sC_train.bufs["targets"], self.sC_eval.bufs["targets"], self.sC_met.bufs["targets"] = lab[2], lab[1], lab[0]
         self.sK_eval.bufs["targets"], self.sK_eval.bufs["targets2"] = lab[3:5].view(-1), lab[5:7].view(-1)
         w_cm = float(self.opt.clean_model_weight)
+        # one head launch per differentiated pass (forward + feature gradient: combat_head_fwd_bwd), where the engine has it
+        hb = FUSED_HEAD and type(eC) is PreActEngine
         self.pl = dict(
-            C_train_f=eC.forward_plan(self.sC_train, True), C_train_b=eC.backward_train_plan(self.sC_train),
-            C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False, split_head=self.merge_c),
+            C_train_f=eC.forward_plan(self.sC_train, True, **(dict(head_bwd=True) if hb else {})),
+            C_train_b=eC.backward_train_plan(self.sC_train, **(dict(head_done=True) if hb else {})),
+            C_eval_f=eC.forward_plan(self.sC_eval, False, 1.0, False, **(dict(split_head=True) if self.merge_c else dict(head_bwd=True) if hb else {})),
         )
         self.pl.update(self._gen_plans())
         self.sC_bd = self.sC_eval.half_view(n, n, eC.FWD_SHARED) if self.merge_c else self.sC_eval
-        self.pl["C_bd_b"] = eC.backward_eval_plan(self.sC_bd, 1.0)
+        self.pl["C_bd_b"] = eC.backward_eval_plan(self.sC_bd, 1.0, **(dict(head_done=True) if hb and not self.merge_c else {}))
         # the second stream's passes run beside the critical queue: one tile per workgroup (engine.short_workgroups)
         with (short_workgroups() if SIDE_SHORT_WORKGROUPS else contextlib.nullcontext()):
             if not self.merge_c:
@@ -691,8 +699,9 @@ class ClassifierStep:
         self.tab_i = torch.zeros(2, n, dtype=torch.int32, device=dev)
         self.tab_f = torch.zeros(n, 4, dtype=f32, device=dev)
         self.slot = self.eC.slot("V.train", n, hw)
-        self.fwd = self.eC.forward_plan(self.slot, True)
-        self.bwd = self.eC.backward_train_plan(self.slot)
+        hb = FUSED_HEAD and type(self.eC) is PreActEngine
+        self.fwd = self.eC.forward_plan(self.slot, True, **(dict(head_bwd=True) if hb else {}))
+        self.bwd = self.eC.backward_train_plan(self.slot, **(dict(head_done=True) if hb else {}))
 
     def run(self, inputs: torch.Tensor, targets_cpu: torch.Tensor, poisoned_cpu: Optional[torch.Tensor] = None,
             lr: Optional[float] = None) -> None:

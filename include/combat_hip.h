@@ -414,6 +414,16 @@ int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t C, const fl
 int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32_t C, const float *W, int32_t classes,
                     const float *logits, const int64_t *targets, float loss_weight, float *dlogits,
                     void *d_feat, float *dW, float *db, void *stream);
+/* combat_head_fwd + the feature half of combat_head_bwd (dlogits, d_feat; d_feat may be NULL) in ONE launch, for a
+ * forward pass whose loss is differentiated right away (train_generator.py:207-208, 231, 251-254): same values as the
+ * two calls.  combat_head_bwd_weights is then the other half of combat_head_bwd (dW += dlogits^T pooled, db += column
+ * sums): nothing on the critical chain reads it, so it can run beside the input-gradient launches. */
+int combat_head_fwd_bwd(const void *feat, int32_t n, int32_t hw, int32_t C, const float *W, const float *b,
+                        int32_t classes, const int64_t *targets, float loss_weight, float *pooled, float *logits,
+                        float *loss_sum, int32_t *correct, const int64_t *targets2, int32_t *correct2,
+                        float *dlogits, void *d_feat, void *stream);
+int combat_head_bwd_weights(const float *dlogits, const float *pooled, int32_t n, int32_t hw, int32_t C,
+                            int32_t classes, float *dW, float *db, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * SGD(momentum, weight_decay, nesterov) over a list of tensors (train_generator.py:123,125,212,255;

@@ -1495,6 +1495,24 @@ def test_head_forward_backward(ops, hw, classes):
     ops.head_bwd(pooled, n, hw, c, dev(w), logits, dev(t), 0.8, dl, dfeat, dw, db)
     assert rel_l2(nchw(dfeat), fr.grad) < 4e-3
     assert rel_l2(dw, wr.grad) < 1e-5 and rel_l2(db, br.grad) < 1e-5
+    # one launch for the forward + the feature gradient (combat_head_fwd_bwd), the weight half on its own
+    # (combat_head_bwd_weights): the same values as the two calls above, bit for bit where nothing is an atomic sum
+    from combat_amd._lib import lib
+    st = torch.cuda.current_stream().cuda_stream
+    logits2, pooled2, dl2, dfeat2 = torch.empty_like(logits), torch.empty_like(pooled), torch.empty_like(dl), torch.empty_like(dfeat)
+    loss2, correct2 = torch.zeros(1, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    wd, bd, td = dev(w), dev(b), dev(t)
+    ops.check(lib.combat_head_fwd_bwd(fb.data_ptr(), n, hw, c, wd.data_ptr(), bd.data_ptr(), classes, td.data_ptr(), 0.8,
+                                      pooled2.data_ptr(), logits2.data_ptr(), loss2.data_ptr(), correct2.data_ptr(), None, None,
+                                      dl2.data_ptr(), dfeat2.data_ptr(), st), "combat_head_fwd_bwd")
+    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+    ops.check(lib.combat_head_bwd_weights(dl2.data_ptr(), pooled2.data_ptr(), n, hw, c, classes, dw2.data_ptr(), db2.data_ptr(), st),
+              "combat_head_bwd_weights")
+    torch.cuda.synchronize()
+    for u, v in ((logits2, logits), (pooled2, pooled), (dl2, dl), (dfeat2, dfeat)):
+        assert torch.equal(u, v)
+    assert int(correct2) == int(correct) and abs(float(loss2) - float(loss)) < 1e-6
+    assert rel_l2(dw2, dw) < 1e-6 and rel_l2(db2, db) < 1e-6
 
 
 def test_sgd_nesterov_multi_tensor(ops):
