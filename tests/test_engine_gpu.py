@@ -936,6 +936,39 @@ def test_preact_train_forward_with_lds_prologue_equals_the_chain(mods):
     assert rel_l2(gb, ga) < 1e-5
 
 
+def test_fused_head_plans_equal_the_two_launch_plans(mods):
+    """PreActEngine.forward_plan(head_bwd=True) + backward_*_plan(head_done=True) (COMBAT_FUSED_HEAD=1 in the steps): the head's
+    forward and feature gradient as one launch, the linear layer's weight gradient on the auxiliary queue -- the feature
+    gradient bit-identical, parameter gradients equal up to the atomic sums of a few weight-gradient launches, the
+    image gradient of the eval pass bit-identical."""
+    nets, ops_ = mods["nets"], mods["ops"]
+    net = seeded(nets.PreActResNet18, 0).cuda()
+    eng = net._net_engine()
+    eng.refresh()
+    x, t = bench_batch(0, bs=32)
+    out = {}
+    for fused in (False, True):
+        slot = eng.slot("head.%d" % fused, 32, 32)
+        ops_.image_to_c8(x.cuda(), eng.input(slot))
+        eng.head_bufs(slot)["targets"].copy_(t)
+        kw_f, kw_b = (dict(head_bwd=True), dict(head_done=True)) if fused else ({}, {})
+        fwd, bwd = eng.forward_plan(slot, True, **kw_f), eng.backward_train_plan(slot, **kw_b)
+        assert sum("head" in w for _, _, w in fwd.calls) == 1 and any(w == "head_bwd.w" for _, _, w in bwd.calls) == fused
+        fwd.run()
+        bwd.run()
+        torch.cuda.synchronize()
+        res = [slot.bufs["g.feat"].clone(), eng.fp.grad.clone(), float(eng.head_bufs(slot)["loss"])]
+        eslot = eng.slot("head.e%d" % fused, 32, 32)
+        ops_.image_to_c8(x.cuda(), eng.input(eslot))
+        eng.head_bufs(eslot)["targets"].copy_(t)
+        eng.forward_plan(eslot, False, 1.0, False, **kw_f).run()
+        eng.backward_eval_plan(eslot, 1.0, **kw_b).run()
+        torch.cuda.synchronize()
+        out[fused] = res + [eslot.bufs["g.img"].clone()]
+    assert torch.equal(out[False][0], out[True][0]) and torch.equal(out[False][3], out[True][3])
+    assert rel_l2(out[True][1], out[False][1]) < 1e-5 and abs(out[True][2] - out[False][2]) < 1e-5
+
+
 def test_step_keeps_a_dropped_pinned_batch_alive(mods):
     """combat_copy3 reads a pinned host batch through its device mapping, unseen by torch's caching
     host allocator.  A caller that drops its per-batch pin_memory() tensor right after run() (a DataLoader with
