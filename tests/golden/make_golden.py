@@ -800,7 +800,7 @@ def golden_end_metric(name="end_metric.npz", threads=8, cfg=None):
 
 # The regime in which the attack TAKES: with the reference's default --noise_rate 0.08 the trigger is a
 # tenth of the class signal of this set and the victim never learns it (Bd ASR = chance, end_metric.npz above: kept as
-# the fast variant).  At --noise_rate 0.3 (a reference flag, config.py:51) and 12 + 12 epochs the clean accuracy still
+# the fast variant).  At --noise_rate 0.3 (a reference flag, config.py:37) and 12 + 12 epochs the clean accuracy still
 # converges (99.5-99.9 %) and eval.py's Bd ASR is 65-75 % (regime found with tools/end_metric_sweep.py on the HIP path;
 # the numbers recorded here are the reference modules' own).
 ATTACK_CFG = dict(noise_rate=0.3, epochs_b=12, epochs_c=12)
