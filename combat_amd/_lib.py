@@ -118,6 +118,10 @@ SIGNATURES = {
     "combat_head_fwd_bwd": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp,
                                       c_vp, c_vp, c_vp, c_vp, c_vp]),
     "combat_head_bwd_weights": (C.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "combat_comm_unique_id": (C.c_int, [c_vp]),
+    "combat_comm_init_rank": (C.c_int, [C.POINTER(c_vp), c_i32, c_vp, c_i32]),
+    "combat_comm_destroy": (C.c_int, [c_vp]),
+    "combat_allreduce": (C.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "combat_sgd_nesterov": (C.c_int, [c_vp, c_vp, c_i32, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "combat_image_to_c8": (C.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp]),
     "combat_nhwc_to_nchw_f32": (C.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libcombat_hip.so")
-SOURCES = ["capi.cpp", "plan.cpp", "conv_gemm.hip", "conv3x3.hip", "conv3x3_dma.hip", "conv_gather_dma.hip", "conv_k8.hip", "conv_wgrad.hip", "conv_wgrad3x3.hip", "conv_wgrad3x3_dma.hip", "norm.hip", "elementwise.hip", "trigger.hip", "head.hip", "warp.hip"]
+SOURCES = ["capi.cpp", "plan.cpp", "comm.cpp", "conv_gemm.hip", "conv3x3.hip", "conv3x3_dma.hip", "conv_gather_dma.hip", "conv_k8.hip", "conv_wgrad.hip", "conv_wgrad3x3.hip", "conv_wgrad3x3_dma.hip", "norm.hip", "elementwise.hip", "trigger.hip", "head.hip", "warp.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result", "-Wno-inline-asm",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("COMBAT_HIPCC_FLAGS", "").split()

@@ -541,6 +541,23 @@ int combat_plan_run(combat_plan *plan, int32_t begin, int32_t end, void *stream,
 int combat_plan_join(combat_plan *plan, void *stream, void *const *aux_streams, int32_t n_aux);
 int32_t combat_plan_failed_call(const combat_plan *plan);
 
+/* ------------------------------------------------------------------------------------------
+ * Gradient exchange of the data-parallel step (no counterpart in the reference, which has no distributed
+ * code): a thin wrapper over RCCL for hosts that are not PyTorch -- the repo's own path uses torch.distributed's "nccl"
+ * backend (= RCCL) on the same flat fp32 gradient buffers.  One communicator per rank-process / GPU: rank 0 calls
+ * combat_comm_unique_id and ships the 128 bytes to the other ranks out of band, every rank calls combat_comm_init_rank;
+ * combat_allreduce sums `count` elements of `buf` in place over the ranks, on `stream` (netC's gradients after Phase C,
+ * netG's after Phase G: train_generator.py:208-212, :253-255 with the exchange in front of the optimiser step).
+ * RCCL is looked up at first use (dlsym among the loaded libraries, else dlopen("librccl.so")): COMBAT_ELAUNCH if absent.
+ * ------------------------------------------------------------------------------------------ */
+#define COMBAT_COMM_UNIQUE_ID_BYTES 128
+#define COMBAT_DTYPE_F32 0
+#define COMBAT_DTYPE_BF16 1
+int combat_comm_unique_id(void *out128);
+int combat_comm_init_rank(void **comm, int32_t nranks, const void *unique_id128, int32_t rank);
+int combat_comm_destroy(void *comm);
+int combat_allreduce(void *buf, int64_t count, int32_t dtype, void *comm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

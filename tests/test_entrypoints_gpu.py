@@ -214,6 +214,20 @@ def test_rccl_streams_beside_the_step_on_one_gpu():
     assert out["ms_with_rccl"] <= 1.5 * out["ms_without"] + 0.1, out
 
 
+def test_c_abi_allreduce_world1():
+    """SURVEY 8(b)'s `combat_allreduce(buf, count, dtype, comm, stream)`: the RCCL wrapper a non-PyTorch host binds
+    (combat_comm_unique_id / _init_rank / _destroy, RCCL resolved with dlsym / dlopen at first use), exercised on the one
+    GPU of the box in a fresh process (tests/rccl_cabi.py)."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "COMBAT_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_cabi.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + "\n" + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["rc"] == [0, 0, 0] and out["refused"] == -1 and out["f32_identity"] and out["bf16_identity"], out
+
+
 def test_bench_spawns_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` outside torchrun starts 2 ranks itself (child torch.distributed.run, gloo
     rehearsal on this one GPU) and rank 0 prints n_gpus = 2."""
