@@ -969,6 +969,43 @@ def test_fused_head_plans_equal_the_two_launch_plans(mods):
     assert rel_l2(out[True][1], out[False][1]) < 1e-5 and abs(out[True][2] - out[False][2]) < 1e-5
 
 
+@pytest.mark.parametrize("switch", ["merge_c_eval", "fused_head", "reduce_behind", "fused_prologue"])
+def test_step_ab_switches_keep_the_results(mods, switch):
+    """Round 4's opt-in forms of the step (all measured no faster; kept selectable): netC's two Phase-G
+    eval forwards as one 2n pass (COMBAT_MERGE_C_EVAL), one head launch per differentiated pass (COMBAT_FUSED_HEAD),
+    weight-gradient reductions carried by the next launch (COMBAT_REDUCE_BEHIND), BatchNorm + ReLU in the consuming
+    convolution's LDS (COMBAT_FUSED_PROLOGUE).  Each must leave a step's losses, counters and updated weights where the
+    default leaves them (up to the summation order of the kernels it swaps)."""
+    step_mod, engine = mods["step"], mods["engine"]
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.randint(0, 256, (32, 3, 32, 32), generator=gen).float() / 255 - 0.5) / 0.5
+    t = torch.randint(0, 10, (32,), generator=gen)
+    t[:5] = 0
+    flags = {"merge_c_eval": (step_mod, "MERGE_C_EVAL"), "fused_head": (step_mod, "FUSED_HEAD"),
+             "reduce_behind": (engine, "REDUCE_BEHIND"), "fused_prologue": (engine, "FUSED_PROLOGUE")}
+    mod, name = flags[switch]
+    out = []
+    for on in (False, True):
+        prev = getattr(mod, name)
+        setattr(mod, name, on)
+        try:
+            netc, clean, netg, netf = _build(mods, [0, 1, 2, 3])
+            st = step_mod.AlternatedStep(netc.cuda(), netg.cuda(), clean.cuda().eval(), netf.cuda().eval(), Opt())
+            for i in range(2):
+                st.run(x.cuda(), t, step_mod.StepRandomness(3, 0.4, 0.7, [None] * 5))
+            torch.cuda.synchronize()
+            out.append((st.read_metrics(), torch.cat([p.detach().flatten() for p in netc.parameters()]).clone(),
+                        torch.cat([p.detach().flatten() for p in netg.parameters()]).clone()))
+        finally:
+            setattr(mod, name, prev)
+    (m0, c0, g0), (m1, c1, g1) = out
+    for k in ("loss_c_sum", "loss_ce_sum", "clean_model_loss_sum", "loss_l2_sum"):
+        assert abs(m0[k] - m1[k]) <= 2e-3 * max(1.0, abs(m0[k])), (switch, k, m0[k], m1[k])
+    for k in ("clean_correct", "bd_correct", "clean_model_correct", "clean_model_bd_ba", "clean_model_bd_asr", "train_correct"):
+        assert abs(m0[k] - m1[k]) <= 1, (switch, k, m0[k], m1[k])
+    assert rel_l2(c1, c0) < 2e-3 and rel_l2(g1, g0) < 2e-3, (switch, rel_l2(c1, c0), rel_l2(g1, g0))
+
+
 def test_step_keeps_a_dropped_pinned_batch_alive(mods):
     """combat_copy3 reads a pinned host batch through its device mapping, unseen by torch's caching
     host allocator.  A caller that drops its per-batch pin_memory() tensor right after run() (a DataLoader with
