@@ -939,7 +939,10 @@ def test_wgrad_reduction_rides_in_the_next_weight_gradient(ops):
     first, second = chain(), chain()
     for i in range(len(layers)):
         assert rel_l2(first[i], alone[i]) < 1e-6, i          # (the stand-alone reduction adds the ranges in another order)
-        assert torch.equal(first[i], second[i]), i            # fixed order, no atomics: bit-reproducible
+        if i + 1 < len(layers):
+            assert torch.equal(first[i], second[i]), i        # carried reduction: fixed order, no atomics: bit-reproducible
+        else:     # (the chain's last launch gets the stand-alone reduction: atomics unless COMBAT_WGRAD_DET_REDUCE=1)
+            assert rel_l2(first[i], second[i]) < 1e-6
     # a stride-2 launch (generic kernel) behind a slab-leaving one: the predecessor is reduced by a launch of its own
     x, dy, pc, shp, _ = layers[0]
     ws = torch.empty(24 << 20, dtype=torch.uint8, device="cuda")
