@@ -158,7 +158,9 @@ __device__ __forceinline__ void reduce_slabs(const float *__restrict__ ws, float
 // loop 44.8 k -> 38.2 k cycles, the launch and the step unchanged -- the 96-KB ring and 226 registers keep the
 // input-gradient chain's workgroups off the CU (72 KB and 162 registers leave them room), and inside the step that
 // sharing, not this loop, sets the pace.
-template <int HPW, int NS>
+// RED: the launch first folds an earlier launch's slabs (reduce_first): its own instantiation, so that the default
+// kernels keep their scalar-register budget (with the fold compiled in they spilled nine SGPRs)
+template <int HPW, int NS, bool RED>
 __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const combat_wgrad_args &a = p.a;
@@ -169,7 +171,7 @@ __device__ __forceinline__ void wgrad3x3_dma_body(const W3dParams &p) {
     // completed).  It used to be a launch of its own behind every weight gradient -- 24 per step, ~11 us each on the
     // auxiliary queue; here it is ~1/128 of the slabs per workgroup (147 KB, mostly from L2 / the Infinity Cache)
     // before the first patch is asked for.
-    if (p.red_ws) {
+    if (RED && p.red_ws) {
         reduce_slabs<512>(p.red_ws, p.red_dw, p.red_base, p.red_tiles_c, p.red_split, p.red_k_real, p.red_c_real, smem, blockIdx.x, gridDim.x);
         __syncthreads();       // (the scratch is the first DMA stage)
     }
@@ -540,15 +542,15 @@ __global__ __launch_bounds__(256) void wgrad3x3_reduce_det_kernel(const float *_
 }
 
 // (the body is a device function: the host pass cannot see the buffer-resource type it uses)
-template <int HPW, int NS>
-__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_dma_kernel(const W3dParams p) { wgrad3x3_dma_body<HPW, NS>(p); }
+template <int HPW, int NS, bool RED>
+__global__ __launch_bounds__(512, 1) void conv_wgrad3x3_dma_kernel(const W3dParams p) { wgrad3x3_dma_body<HPW, NS, RED>(p); }
 
-template <int HPW, int NS>
-int launch_w3d(const W3dParams &p, int blocks, hipStream_t st) {
+template <int HPW, int NS, bool RED>
+int launch_w3d_red(const W3dParams &p, int blocks, hipStream_t st) {
     constexpr int stage = 8192 + HPW * 8192;
     constexpr int ep = 64 * 68 * 4;
     constexpr int smem = NS * stage > ep ? NS * stage : ep;
-    auto kern = conv_wgrad3x3_dma_kernel<HPW, NS>;
+    auto kern = conv_wgrad3x3_dma_kernel<HPW, NS, RED>;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -558,6 +560,11 @@ int launch_w3d(const W3dParams &p, int blocks, hipStream_t st) {
     COMBAT_LAUNCH(kern, dim3(blocks), dim3(512), smem, st, p);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;
+}
+
+template <int HPW, int NS>
+int launch_w3d(const W3dParams &p, int blocks, hipStream_t st) {
+    return p.red_ws ? launch_w3d_red<HPW, NS, true>(p, blocks, st) : launch_w3d_red<HPW, NS, false>(p, blocks, st);
 }
 
 bool w3d_geometry(const combat_wgrad_args *a, W3dParams &p, int &smem) {
