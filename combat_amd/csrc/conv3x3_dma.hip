@@ -78,9 +78,45 @@ struct DGeo {
     // columns, so the key is (column bit 1, row parity) there -- with the column key alone every fragment read
     // was a 2-way bank conflict (LdsBankConflict 0.50 in the PMC pass, 0.03-0.06 on the other geometries).
     static constexpr int HWP = TW == 4 ? 8 : TW + 2;
-    static constexpr int HROWS = TI * HH * HWP;                  // LDS rows (pixels) of one halo image
+    // WHOLE (4 x 4 and 8 x 8 maps): a tile is TI whole images, so its halo is nothing but padding, and the padding is
+    // not DMA'd.  The LDS image holds each image's TW * TH pixels back to back (pitch TW), one image row of zeros
+    // above the first image and below every image (the filter rows that leave the image read those), and a zone of
+    // zeros behind the last one which the fragment reads of a filter COLUMN that leaves the image are pointed at
+    // (fixed per lane and column offset, see `pa`; three rows one filter-row stride apart).  The zeros are written
+    // once, when the kernel starts; the DMA pieces -- 8 rows = TW 8: one image row, TW 4: two -- carry data only:
+    // 4 per wave and chunk where the padded form (rows of pitch 8 / 10 with the padding fetched as out-of-range
+    // loads) issued 12 / 7, and 22 KB per image where that took 48 / 28 (TW 4: 109 KB per workgroup = one per CU and
+    // no other queue's convolution beside it).  Measured against the padded form on one box: 512 -> 512 at 4 x 4
+    // 16.3 -> 14.6 us back to back, 22.5 -> 20.7 cold; 256 -> 256 at 8 x 8 unchanged (14.6); the step 3.727 -> 3.699 ms.
+    static constexpr bool WHOLE = TW == 4 || TW == 8;
+    static constexpr int IPITCH = TW * TH + TW;                  // WHOLE: LDS rows from one image to the next
+    static constexpr int ZONE = (TW + TI * IPITCH) * 128;        // WHOLE: byte offset of the zone of zeros
+    static constexpr int HROWS = WHOLE ? BM : TI * HH * HWP;     // LDS rows (pixels) the DMA fills in one halo image
     static constexpr int HPW = (HROWS + 8 * NW - 1) / (8 * NW);  // 1-KiB DMA pieces (8 rows) per wave
-    static constexpr int HBYTES = HPW * NW * 1024;               // every wave issues the same number of pieces
+    // (every wave issues the same number of pieces)
+    static constexpr int HBYTES = WHOLE ? (ZONE + (2 * TW + 1) * 128 + 1023) / 1024 * 1024 : HPW * NW * 1024;
+    // LDS row of row `sub` (0..7) of DMA piece k
+    static __device__ __forceinline__ int piece_row(int k, int sub) {
+        if constexpr (WHOLE) {
+            const int d = k * 8 + sub;                           // data row: image * (TW * TH) + y * TW + x
+            return TW + (d / (TW * TH)) * IPITCH + d % (TW * TH);
+        } else {
+            return k * 8 + sub;
+        }
+    }
+    // LDS row -> (image of the tile, halo row, halo column); halo coordinates = pixel coordinates + 1
+    static __device__ __forceinline__ void halo_pos(int row, int &ti, int &hy, int &hx) {
+        if constexpr (WHOLE) {
+            const int r = row - TW;
+            ti = r / IPITCH;
+            const int w = r % IPITCH;
+            hy = w / TW + 1, hx = w % TW + 1;
+        } else {
+            hx = row % HWP;
+            const int t = row / HWP;
+            hy = t % HH, ti = t / HH;
+        }
+    }
     static constexpr int TW_SHIFT = TW == 16 ? 4 : (TW == 8 ? 3 : 2);
     static constexpr int TH_SHIFT = TH == 32 ? 5 : (TH == 16 ? 4 : (TH == 8 ? 3 : 2));
 };
@@ -189,6 +225,14 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     const int C = a.C, H = a.H, W = a.W;
     unsigned char *halo = smem;
     unsigned char *wring = smem + HB * HBYTES;
+    if constexpr (G::WHOLE) {   // the zeros of each halo image (no DMA ever writes them; first read after the first barrier)
+        constexpr int NPAD = G::TI + 1, PADU = TW * 8, ZU = (2 * TW + 1) * 8;   // 16-byte units: one padding row group / the zone
+        for (int u = tid; u < HB * (NPAD * PADU + ZU); u += 64 * NW) {
+            const int hb_ = u / (NPAD * PADU + ZU), v = u % (NPAD * PADU + ZU);
+            const int off = v < NPAD * PADU ? (v / PADU) * G::IPITCH * 128 + (v % PADU) * 16 : G::ZONE + (v - NPAD * PADU) * 16;
+            *reinterpret_cast<u32x4_t *>(halo + hb_ * HBYTES + off) = u32x4_t{0u, 0u, 0u, 0u};
+        }
+    }
 
     const __amdgpu_buffer_rsrc_t srsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.src), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wpack), 0, p.w_bytes, 0x00020000);
@@ -238,21 +282,21 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     unsigned hvoff[HPW];
 #pragma unroll
     for (int j = 0; j < HPW; ++j) {
-        const int row = (wid + NW * j) * 8 + (lane >> 3), slot = lane & 7;
-        const int hx = row % G::HWP, t = row / G::HWP;
-        const int hy = t % G::HH, ti = t / G::HH;
+        const int row = G::piece_row(wid + NW * j, lane >> 3), slot = lane & 7;
+        int ti, hy, hx;
+        G::halo_pos(row, ti, hy, hx);
         // slot rotation of this halo position (see the fragment reads): by column; on 4-wide maps, where a
         // fragment's 16 pixels are four rows of the same four columns, by column bit 1 and row parity
         const int rot = TW == 4 ? ((hx & 2) + ((hy & 1) << 2)) : (hx & 6);
         const int chunk = (slot - rot) & 7;
         const int img = img0 + ti, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-        const bool ok = row < G::HROWS && hx < TW + 2 && img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const bool ok = (G::WHOLE || (row < G::HROWS && hx < TW + 2)) && img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
         hvoff[j] = ok ? (unsigned)((((img * H + iy) * W + ix) * C + chunk * 8) * 2) : kOob;
     }
     auto issue_h = [&](int cc, int hbuf) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < (cc == 0 ? HPW : ABL_DMA(HPW)); ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(halo + hbuf * HBYTES + (wid + NW * j) * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srsrc, (lds_void_t *)(halo + hbuf * HBYTES + G::piece_row(wid + NW * j, 0) * 128), 16,
                                                      hvoff[j], cc * 128, 0, 0);
     };
     issue_h(0, 0);
@@ -270,13 +314,13 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
         const int g = lane & 7;
 #pragma unroll
         for (int j = 0; j < HPW; ++j) {
-            const int row = (wid + NW * j) * 8 + (lane >> 3);
-            const int hx = row % G::HWP, t = row / G::HWP;
-            const int hy = t % G::HH, ti = t / G::HH;
+            const int row = G::piece_row(wid + NW * j, lane >> 3);
+            int ti, hy, hx;
+            G::halo_pos(row, ti, hy, hx);
             const int rot = TW == 4 ? ((hx & 2) + ((hy & 1) << 2)) : (hx & 6);
             taddr[j] = row * 128 + ((g + rot) & 7) * 16;
             const int img = img0 + ti, iy = oy0 + hy - 1, ix = ox0 + hx - 1;
-            const bool ok = row < G::HROWS && hx < TW + 2 && img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const bool ok = (G::WHOLE || (row < G::HROWS && hx < TW + 2)) && img < a.N && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             tvalid |= ok ? (1u << j) : 0u;
             const bool interior = ok && hx >= 1 && hx <= TW && hy >= 1 && hy <= G::TH && tile_n == 0;
             aoff[j] = interior ? (unsigned)((((img * H + iy) * W + ix) * C + g * 8) * 2) : kOob;
@@ -331,13 +375,16 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     for (int j = 0; j < T::FM; ++j) {
         const int pj = wid * RPW + j * 16 + (lane & 15);
         const int tx = pj & (TW - 1), ty = (pj >> G::TW_SHIFT) & (G::TH - 1), ti = pj >> (G::TW_SHIFT + G::TH_SHIFT);
-        const int r0 = (ti * G::HH + ty) * G::HWP + tx;
+        // (WHOLE: the row above the pixel's, one column to the left -- filter row 0 of the first image reads the
+        // padding row in front of it; a column offset that leaves the image reads the zone of zeros)
+        const int r0 = G::WHOLE ? ti * G::IPITCH + ty * TW + tx - 1 : (ti * G::HH + ty) * G::HWP + tx;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int rot = TW == 4 ? (((tx + dx) & 2) + ((ty & 1) << 2)) : ((tx + dx) & 6);   // (TW 4: for filter row 0)
             const int s0 = ((lane >> 4) + rot) & 7;
-            pa[0][j][dx] = (r0 + dx) * 128 + s0 * 16;
-            pa[1][j][dx] = (r0 + dx) * 128 + (s0 ^ 4) * 16;
+            const bool in = !G::WHOLE || (tx + dx >= 1 && tx + dx <= TW);
+            pa[0][j][dx] = in ? (r0 + dx) * 128 + s0 * 16 : G::ZONE;
+            pa[1][j][dx] = in ? (r0 + dx) * 128 + (s0 ^ 4) * 16 : G::ZONE;
         }
     }
     int wa[2];
@@ -358,7 +405,7 @@ __device__ __forceinline__ void conv3x3_dma_body(const DmaParams &p) {
     auto read_frags = [&](bf16x8_t (&fp)[T::FM], bf16x8_t (&fw)[T::FN], auto t_tag, auto ks_tag, auto hbuf_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value, ks = decltype(ks_tag)::value, hbuf = decltype(hbuf_tag)::value;
         constexpr int dy = t / 3, dx = t % 3;
-        const unsigned char *hb = halo + hbuf * HBYTES + dy * G::HWP * 128;
+        const unsigned char *hb = halo + hbuf * HBYTES + dy * (G::WHOLE ? TW : G::HWP) * 128;
         const unsigned char *wb = wring + (t % 3) * WBYTES;
         // TW 4: an odd filter row flips the row parity of the rotation key = the other k-step's slot (s0 ^ 4)
         constexpr int kk = (TW == 4 && (dy & 1)) ? (ks ^ 1) : ks;
@@ -1171,10 +1218,10 @@ int conv3x3d_pick(const combat_conv_args *a) {
     // one workgroup per CU (a workgroup alone on a CU issues in order: DMA pieces ~100 cycles each, then
     // fragment reads, then MFMAs; a second one fills those gaps: 5-6 % on the 256-tile shapes).  (256-pixel tiles -- eight waves, half the weight DMA per MFMA -- exist for explicit requests
     // only: measured 0-15 % slower than three co-resident 128-pixel workgroups on every layer shape.)
-    // (4-pixel-wide maps: two halo images of 8 x 6 x 8 pixels leave room for one workgroup per CU whatever BN is,
-    // so there 32-channel tiles only pay while the 64-channel ones leave CUs empty)
+    // (4-pixel-wide maps kept 64-channel tiles at 193-256 workgroups while their padded halo images allowed one
+    // workgroup per CU whatever BN was; with the whole-image form the two tie in the step)
     const long wgs64 = tiles_m_of(a) * (a->K / 64);
-    return wgs64 < 192 || (wgs64 <= 256 && geo_tw(a) > 4) ? COMBAT_TILE_D128x32 : COMBAT_TILE_D128x64;
+    return wgs64 <= 256 ? COMBAT_TILE_D128x32 : COMBAT_TILE_D128x64;
 }
 
 int conv3x3d_stats_layout(const combat_conv_args *a, int tile, int *rows, int *rows_per_image) {
