@@ -74,6 +74,8 @@ class BnDesc(C.Structure):
 SIGNATURES = {
     "combat_version": (C.c_char_p, []),
     "combat_abi_version": (C.c_int, []),
+    "combat_set_deterministic": (None, [C.c_int]),
+    "combat_get_deterministic": (C.c_int, []),
     "combat_conv_gemm": (C.c_int, [C.POINTER(ConvArgs), c_vp]),
     "combat_conv_gemm_pair": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), c_vp]),
     "combat_conv_workspace_bytes": (c_i64, [C.POINTER(ConvArgs)]),

@@ -102,6 +102,11 @@ __device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// combat_set_deterministic / COMBAT_DETERMINISTIC=1 (capi.cpp): launches pick their order-independent forms
+bool combat_deterministic();
+// <= 2 MB of library-owned scratch per stream for two-stage reductions (capi.cpp); nullptr if `bytes` exceeds it
+float *combat_stream_scratch(void *stream, size_t bytes);
+
 static inline int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;
     int s = 0;

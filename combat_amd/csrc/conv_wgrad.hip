@@ -221,6 +221,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             }
     }
     __syncthreads();
+    if (p.ws) {   // deterministic mode: this pixel range's tile as a slab; wgrad_slab_reduce_kernel sums the ranges in order
+        float *slab = p.ws + ((((size_t)sp * p.ntaps + tap) * p.tiles_k + tile_k) * p.tiles_c + tile_c) * (size_t)(BMC * BNC);
+        for (int idx = tid; idx < BMC * BNC; idx += 256) {
+            const int row = idx / BNC, col = idx - row * BNC;
+            slab[idx] = ep[row * T::EPS + col];
+        }
+        return;
+    }
     const int creal = a.c_real;
     for (int idx = tid; idx < BMC * BNC; idx += 256) {
         const int row = idx / BNC, col = idx - row * BNC;
@@ -391,7 +399,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_c8_kernel(const WgradParams p)
 // dw[(k0 + row)][tap][c] += sum over pixel ranges of the slabs [range][k tile][64][9][creal]
 __global__ __launch_bounds__(256) void conv_wgrad_c8_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw,
                                                                    int tiles_k, int split, int per_tile, int k_real,
-                                                                   int row_elems) {
+                                                                   int row_elems, float *__restrict__ part) {
     // blockIdx.z = one of gridDim.z interleaved groups of pixel ranges (a thread walking all of them alone is a
     // chain of `split` dependent round trips); the groups meet in dw with a handful of atomics per element
     const int e = blockIdx.x * 256 + threadIdx.x, tile_k = blockIdx.y;
@@ -408,7 +416,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_c8_reduce_kernel(const float *
         s3 += ws[((size_t)(sp + 3 * G) * tiles_k + tile_k) * per_tile + e];
     }
     for (; sp < split; sp += G) s0 += ws[((size_t)sp * tiles_k + tile_k) * per_tile + e];
-    atomicAdd(dw + (size_t)tile_k * per_tile + e, (s0 + s1) + (s2 + s3));
+    const float s = (s0 + s1) + (s2 + s3);
+    if (part) part[((size_t)blockIdx.z * tiles_k + tile_k) * per_tile + e] = s;   // deterministic mode: a second pass adds the groups in order
+    else atomicAdd(dw + (size_t)tile_k * per_tile + e, s);
 }
 
 int launch_c8(WgradParams p, hipStream_t st) {
@@ -436,14 +446,66 @@ int launch_c8(WgradParams p, hipStream_t st) {
     const int per_tile = 64 * 9 * p.a.c_real;
     const long need = (long)p.tiles_k * p.split * per_tile * 4;
     p.ws = (p.split > 1 && p.a.workspace && p.a.workspace_bytes >= need) ? reinterpret_cast<float *>(p.a.workspace) : nullptr;
+    if (combat_deterministic() && p.split > 1 && !p.ws) return COMBAT_EINVAL;
     COMBAT_LAUNCH(conv_wgrad_c8_kernel, dim3((unsigned)(p.tiles_k * p.split)), dim3(256), SMEM, st, p);
     CB_LAUNCH_CHECK();
     if (p.ws) {
-        COMBAT_LAUNCH(conv_wgrad_c8_reduce_kernel, dim3((per_tile + 255) / 256, p.tiles_k, p.split >= 32 ? 16 : 1), dim3(256), 0, st, p.ws,
-                           p.a.dw, p.tiles_k, p.split, per_tile, p.a.k_real, 9 * p.a.c_real);
+        const int groups = p.split >= 32 ? 16 : 1;
+        // deterministic mode: the 16 groups' sums go behind the slabs and a second pass (one group: one add per element)
+        // adds them in order; without room for that, one group walks every range
+        float *part = nullptr;
+        if (combat_deterministic() && groups > 1) {
+            const long extra = (long)groups * p.tiles_k * per_tile * 4;
+            if (p.a.workspace_bytes >= need + extra) part = p.ws + need / 4;
+        }
+        const int g1 = combat_deterministic() && !part ? 1 : groups;
+        COMBAT_LAUNCH(conv_wgrad_c8_reduce_kernel, dim3((per_tile + 255) / 256, p.tiles_k, g1), dim3(256), 0, st, (const float *)p.ws,
+                           p.a.dw, p.tiles_k, p.split, per_tile, p.a.k_real, 9 * p.a.c_real, part);
         CB_LAUNCH_CHECK();
+        if (part) {
+            COMBAT_LAUNCH(conv_wgrad_c8_reduce_kernel, dim3((per_tile + 255) / 256, p.tiles_k, 1), dim3(256), 0, st, (const float *)part,
+                               p.a.dw, p.tiles_k, groups, per_tile, p.a.k_real, 9 * p.a.c_real, (float *)nullptr);
+            CB_LAUNCH_CHECK();
+        }
     }
     return COMBAT_OK;
+}
+
+// Deterministic mode: dw[n][tap][c] += sum over the pixel ranges (ascending) of the slabs conv_wgrad_kernel left --
+// one thread per gradient element, sole owner of it; the hi / lo image channels (c and c + c_real of an 8-channel
+// input, c_real < C) fold onto the real one here.
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dw, int split,
+                                                                int ntaps, int tiles_k, int tiles_c, int bmc, int bnc, int k_real,
+                                                                int c_real, int C) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)k_real * ntaps * c_real) return;
+    const int c = (int)(e % c_real), tap = (int)((e / c_real) % ntaps), n = (int)(e / ((long)c_real * ntaps));
+    const int tile_k = n / bmc, row = n - tile_k * bmc;
+    const size_t tile_elems = (size_t)bmc * bnc, sstride = (size_t)ntaps * tiles_k * tiles_c * tile_elems;
+    float total = 0.f;
+    for (int half = 0; half < 2; ++half) {
+        const int cs = c + half * c_real;
+        if (half && (c_real >= C || cs >= C || cs >= 2 * c_real)) break;
+        const int tile_c = cs / bnc, col = cs - tile_c * bnc;
+        const float *src = ws + (((size_t)tap * tiles_k + tile_k) * tiles_c + tile_c) * tile_elems + (size_t)row * bnc + col;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int sp = 0;
+        for (; sp + 4 <= split; sp += 4) {      // four loads in flight; the order of the additions is fixed
+            s0 += src[(size_t)sp * sstride];
+            s1 += src[(size_t)(sp + 1) * sstride];
+            s2 += src[(size_t)(sp + 2) * sstride];
+            s3 += src[(size_t)(sp + 3) * sstride];
+        }
+        for (; sp < split; ++sp) s0 += src[(size_t)sp * sstride];
+        total += (s0 + s1) + (s2 + s3);
+    }
+    dw[e] += total;
+}
+
+template <int BMC, int BNC>
+int64_t generic_slab_bytes(const combat_wgrad_args &a, int split) {
+    const long tiles_k = (a.K + BMC - 1) / BMC, tiles_c = (a.C + BNC - 1) / BNC;
+    return (int64_t)split * a.R * a.S * tiles_k * tiles_c * BMC * BNC * 4;
 }
 
 template <int BMC, int BNC>
@@ -475,15 +537,80 @@ int launch(WgradParams p, hipStream_t st) {
     p.pix_per_split = ((ktiles + split - 1) / split) * 64;
     p.split = (p.M + p.pix_per_split - 1) / p.pix_per_split;
     const long blocks = (long)p.tiles_k * p.tiles_c * p.ntaps * p.split;
+    p.ws = nullptr;
+    if (combat_deterministic() && p.split > 1) {   // (one pixel range: one atomic add per element, nothing to order)
+        const int64_t need = generic_slab_bytes<BMC, BNC>(p.a, p.split);
+        if (!p.a.workspace || p.a.workspace_bytes < need) return COMBAT_EINVAL;
+        p.ws = reinterpret_cast<float *>(p.a.workspace);
+    }
     COMBAT_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), T::SMEM, st, p);
     CB_LAUNCH_CHECK();
+    if (p.ws) {
+        const long elems = (long)p.a.k_real * p.ntaps * p.a.c_real;
+        COMBAT_LAUNCH(wgrad_slab_reduce_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, (const float *)p.ws, p.a.dw,
+                      p.split, p.ntaps, p.tiles_k, p.tiles_c, BMC, BNC, p.a.k_real, p.a.c_real, p.a.C);
+        CB_LAUNCH_CHECK();
+    }
     return COMBAT_OK;
+}
+
+// pixel ranges the generic kernel would use (the rule of launch<>, without launching)
+template <int BMC, int BNC>
+int generic_split(const combat_wgrad_args &a) {
+    const long M = (long)a.N * a.P * a.Q;
+    const int ktiles = (int)((M + 63) / 64), ntaps = a.R * a.S;
+    const int tiles_k = (a.K + BMC - 1) / BMC, tiles_c = (a.C + BNC - 1) / BNC;
+    int split = a.split > 0 ? a.split : 0;
+    if (split <= 0) {
+        const int base = tiles_k * tiles_c * ntaps;
+        split = ((BMC == 16 ? 2304 : 256) + base - 1) / base;
+        const int max_split = (ktiles + 3) / 4;
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+    }
+    if (split > ktiles) split = ktiles;
+    const int pix_per_split = ((ktiles + split - 1) / split) * 64;
+    return (int)((M + pix_per_split - 1) / pix_per_split);
+}
+
+bool c8_applies(const combat_wgrad_args *a) {
+    return a->split >= 0 && a->C == 8 && a->R == 3 && (a->K & 63) == 0 && !a->pro_scale && !a->pro_act;
+}
+
+int64_t c8_workspace(const combat_wgrad_args &a) {   // launch_c8's rule
+    const long M = (long)a.N * a.P * a.Q;
+    const int ktiles = (int)((M + 63) / 64), tiles_k = a.K / 64;
+    int split = a.split;
+    if (split <= 0) {
+        split = (256 + tiles_k - 1) / tiles_k;
+        const int max_split = (ktiles + 3) / 4;
+        if (split > max_split) split = max_split;
+        if (split < 1) split = 1;
+    }
+    if (split > ktiles) split = ktiles;
+    const int pix_per_split = ((ktiles + split - 1) / split) * 64;
+    const long nsplit = (M + pix_per_split - 1) / pix_per_split;
+    if (nsplit <= 1) return 0;
+    const int64_t per_tile = 64 * 9 * a.c_real * 4;
+    return tiles_k * nsplit * per_tile + (nsplit >= 32 ? 16 * tiles_k * per_tile : 0);   // slabs + the 16 groups' sums
+}
+
+int64_t generic_workspace(const combat_wgrad_args &a) {
+    if (a.C <= 16) return generic_slab_bytes<64, 16>(a, generic_split<64, 16>(a));
+    if (a.K <= 16) return generic_slab_bytes<16, 64>(a, generic_split<16, 64>(a));
+    if (a.C % 128 == 0 && a.K % 128 == 0) return generic_slab_bytes<128, 128>(a, generic_split<128, 128>(a));
+    return generic_slab_bytes<64, 64>(a, generic_split<64, 64>(a));
 }
 
 }  // namespace
 
 extern "C" int64_t combat_conv_wgrad_workspace_bytes(const combat_wgrad_args *a) {
-    return a && a->split >= 0 ? (int64_t)conv_wgrad3x3_dma_workspace(a) : 0;
+    if (!a) return 0;
+    const int64_t dma = a->split >= 0 ? (int64_t)conv_wgrad3x3_dma_workspace(a) : 0;
+    if (dma > 0 || !combat_deterministic()) return dma;
+    // deterministic mode: the generic kernel's slabs (layers the DMA-staged 3x3 kernel does not take; the 8-channel
+    // kernel sizes its own slabs inside whatever workspace it is given)
+    return c8_applies(a) ? c8_workspace(*a) : generic_workspace(*a);
 }
 
 static int validate_wgrad_args(const combat_wgrad_args *a) {
@@ -523,12 +650,12 @@ extern "C" int combat_conv_wgrad(const combat_wgrad_args *a, void *stream) {
         const int rc = combat_conv_wgrad_reduce(a->reduce_first, stream);
         if (rc != COMBAT_OK) return rc;
     }
-    if (a->split >= 0) {
+    if (a->split >= 0 && !combat_deterministic()) {   // (register-staged 3x3: its pixel ranges meet through fp32 atomics only)
         const int rc = conv_wgrad3x3_try(a, st);
         if (rc <= 0) return rc;
     }
     if (a->split < 0) p.a.split = 0;
-    if (a->split >= 0 && a->C == 8 && a->R == 3 && (a->K & 63) == 0 && !a->pro_scale && !a->pro_act) return launch_c8(p, st);
+    if (c8_applies(a)) return launch_c8(p, st);
     if (a->C <= 16) return launch<64, 16>(p, st);
     if (a->K <= 16) return launch<16, 64>(p, st);
     if (a->C % 128 == 0 && a->K % 128 == 0) return launch<128, 128>(p, st);

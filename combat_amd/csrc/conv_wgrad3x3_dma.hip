@@ -647,12 +647,17 @@ int launch_reduce(const combat_wgrad_args *a, const W3dParams &p, hipStream_t st
     // 4-8 us back to back.  COMBAT_WGRAD_DET_REDUCE=1: reduce_slabs() as a launch of its own -- fixed summation order, no
     // atomics, bit-reproducible -- 9-18 us (tools/wgrad_chain_bench.py): a workgroup owns whole elements, so the slabs
     // of an element cannot be spread over the chip.
-    static const bool atomics = getenv("COMBAT_WGRAD_DET_REDUCE") == nullptr;
+    static const bool env_det = getenv("COMBAT_WGRAD_DET_REDUCE") != nullptr;
+    const bool det = combat_deterministic();
+    // deterministic mode: with >= 4 tiles (144 workgroups of 256 quads) ONE group of ranges fills enough of the chip
+    // and owns its elements (`dw += sum`, ranges in ascending order, no atomics): the round-3 kernel as it is; the
+    // 64-channel layers (one tile, up to 256 ranges) take reduce_slabs(), which spreads an element's slabs over lanes
+    const bool atomics = !env_det && (!det || base >= 4);
     if (atomics) {
         // enough workgroups to fill the chip; each group of ranges costs one fp32 atomic per element
         const long e4 = (long)base * 9 * 1024;
         int groups = (int)(512 / ((e4 + 255) / 256));
-        if (groups < 1) groups = 1;
+        if (groups < 1 || det) groups = 1;
         if (groups > p.split) groups = p.split;
         COMBAT_LAUNCH(wgrad3x3_reduce_kernel, dim3((unsigned)((e4 + 255) / 256), groups), dim3(256), 0, st, p.ws, a->dw, base,
                            p.tiles_c, p.split, a->k_real, a->c_real);
@@ -688,6 +693,9 @@ bool fill_reduce_first(const combat_wgrad_args *prev, W3dParams &p) {
 int conv_wgrad3x3_dma_try(const combat_wgrad_args *a, hipStream_t st) {
     W3dParams p;
     if (!w3d_plan(a, p)) return 1;
+    // deterministic mode: several pixel ranges meet through slabs (the kernel's other epilogue adds every range's tile
+    // to dw with fp32 atomics)
+    if (combat_deterministic() && !p.ws && p.split > 1) return COMBAT_EINVAL;
     if (!fill_reduce_first(a->reduce_first, p)) return COMBAT_EINVAL;
 #ifdef COMBAT_STAMPS
     p.stamps = g_stamps_wgrad_host;

@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
 
 // ------------------------------------------------------------------ column sums
 __global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ x, long rows, int C, int c_out,
-                                                     float *__restrict__ out) {
-    // one block per 8-channel chunk; deterministic tree over the block
+                                                     float *__restrict__ out, float *__restrict__ part) {
+    // one block per 8-channel chunk and row group; deterministic tree over the block
     __shared__ float sh[256][8];
     const int c = blockIdx.x * 8;
     float s[8];
@@ -167,7 +167,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16 *__restrict__ 
         }
         __syncthreads();
     }
-    if (threadIdx.x < 8 && c + (int)threadIdx.x < c_out) atomicAdd(out + c + threadIdx.x, sh[0][threadIdx.x]);
+    // part != nullptr: this row group's sums as row blockIdx.y of part[gridDim.y][C] (colsum_finish_kernel adds the
+    // groups in order); else (one row group) straight into out
+    if (threadIdx.x < 8) {
+        if (part) part[(long)blockIdx.y * C + c + threadIdx.x] = sh[0][threadIdx.x];
+        else if (c + (int)threadIdx.x < c_out) out[c + threadIdx.x] = sh[0][threadIdx.x];
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restrict__ part, int groups, int C, int c_out,
+                                                            float *__restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= c_out) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int y = 0;
+    for (; y + 4 <= groups; y += 4) {
+        s0 += part[(long)y * C + c];
+        s1 += part[(long)(y + 1) * C + c];
+        s2 += part[(long)(y + 2) * C + c];
+        s3 += part[(long)(y + 3) * C + c];
+    }
+    for (; y < groups; ++y) s0 += part[(long)y * C + c];
+    out[c] = (s0 + s1) + (s2 + s3);
 }
 
 // ------------------------------------------------------------------ max pool / ELU+affine
@@ -632,12 +653,19 @@ extern "C" int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_o
     COMBAT_PLAN_HOOK(combat_colsum, x, rows, C, c_out, out);
     if (!x || !out || rows <= 0 || C <= 0 || (C & 7) || c_out <= 0 || c_out > C) return COMBAT_EINVAL;
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(out, 0, sizeof(float) * c_out, st) != hipSuccess) return COMBAT_ELAUNCH;
     long ysplit = (rows + 2047) / 2048;   // ~8 rows per thread
     if (ysplit > 512) ysplit = 512;
+    // the row groups' sums meet in a second launch, in a fixed order (they used to meet in `out` through fp32 atomics:
+    // a bias gradient that differed in the last bits from run to run); library-owned scratch of this stream
+    float *part = ysplit > 1 ? combat_stream_scratch(stream, (size_t)ysplit * C * sizeof(float)) : nullptr;
+    if (ysplit > 1 && !part) ysplit = 1;
     COMBAT_LAUNCH(colsum_kernel, dim3((c_out + 7) / 8, (unsigned)ysplit), dim3(256), 0, st,
-                       reinterpret_cast<const __bf16 *>(x), (long)rows, C, c_out, out);
+                       reinterpret_cast<const __bf16 *>(x), (long)rows, C, c_out, out, part);
     CB_LAUNCH_CHECK();
+    if (part) {
+        COMBAT_LAUNCH(colsum_finish_kernel, dim3((c_out + 255) / 256), dim3(256), 0, st, (const float *)part, (int)ysplit, C, c_out, out);
+        CB_LAUNCH_CHECK();
+    }
     return COMBAT_OK;
 }
 

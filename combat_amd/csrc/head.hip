@@ -194,25 +194,56 @@ __global__ __launch_bounds__(256) void head_bwd_feat_kernel(const float *__restr
     }
 }
 
-// dW[j][i] += sum_s dlogits[s][j] * pooled[s][i];  db[j] += sum_s dlogits[s][j]   (blockIdx.z: sample range;
-// the gradient buffer is zeroed at the start of every backward pass)
+// dW[j][i] += sum_s dlogits[s][j] * pooled[s][i];  db[j] += sum_s dlogits[s][j]   (blockIdx.z: sample range; the
+// gradient buffer is zeroed at the start of every backward pass).  part != nullptr: a range's sums go to row blockIdx.z
+// of part[gridDim.z][classes * in + classes] and head_bwd_w_finish_kernel adds the ranges in order -- the ranges used
+// to meet in dW through fp32 atomics; else (one range) one add per element.
 __global__ __launch_bounds__(256) void head_bwd_w_kernel(const float *__restrict__ dlogits,
                                                          const float *__restrict__ pooled, int n, int in, int classes,
-                                                         float *__restrict__ dW, float *__restrict__ db) {
+                                                         float *__restrict__ dW, float *__restrict__ db, float *__restrict__ part) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int j = blockIdx.y;
     const int per = (n + gridDim.z - 1) / gridDim.z;
     const int s0 = blockIdx.z * per, s1 = s0 + per < n ? s0 + per : n;
+    float *prow = part ? part + (long)blockIdx.z * ((long)classes * in + classes) : nullptr;
     if (i < in) {
         float s = 0.f;
         for (int smp = s0; smp < s1; ++smp) s = fmaf(dlogits[(long)smp * classes + j], pooled[(long)smp * in + i], s);
-        atomicAdd(dW + (long)j * in + i, s);
+        if (prow) prow[(long)j * in + i] = s;
+        else dW[(long)j * in + i] += s;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         float s = 0.f;
         for (int smp = s0; smp < s1; ++smp) s += dlogits[(long)smp * classes + j];
-        atomicAdd(db + j, s);
+        if (prow) prow[(long)classes * in + j] = s;
+        else db[j] += s;
     }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_w_finish_kernel(const float *__restrict__ part, int ranges, int in, int classes,
+                                                                float *__restrict__ dW, float *__restrict__ db) {
+    const long total = (long)classes * in + classes, e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    float s = 0.f;
+    for (int z = 0; z < ranges; ++z) s += part[(long)z * total + e];
+    if (e < (long)classes * in) dW[e] += s;
+    else db[e - (long)classes * in] += s;
+}
+
+int launch_head_bwd_w(const float *dlogits, const float *pooled, int n, int in, int classes, float *dW, float *db, void *stream) {
+    constexpr int kRanges = 8;
+    float *part = combat_stream_scratch(stream, (size_t)kRanges * ((size_t)classes * in + classes) * sizeof(float));
+    hipStream_t st = as_stream(stream);
+    COMBAT_LAUNCH(head_bwd_w_kernel, dim3((in + 255) / 256, classes, part ? kRanges : 1), dim3(256), 0, st, dlogits, pooled, n, in,
+                       classes, dW, db, part);
+    CB_LAUNCH_CHECK();
+    if (part) {
+        const long total = (long)classes * in + classes;
+        COMBAT_LAUNCH(head_bwd_w_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float *)part, kRanges, in,
+                           classes, dW, db);
+        CB_LAUNCH_CHECK();
+    }
+    return COMBAT_OK;
 }
 
 }  // namespace
@@ -264,9 +295,8 @@ extern "C" int combat_head_bwd(const float *pooled, int32_t n, int32_t hw, int32
     CB_LAUNCH_CHECK();
     if (dW) {
         const int in = C * (hw / 4) * (hw / 4);
-        COMBAT_LAUNCH(head_bwd_w_kernel, dim3((in + 255) / 256, classes, 8), dim3(256), 0, st, dlogits, pooled, n, in,
-                           classes, dW, db);
-        CB_LAUNCH_CHECK();
+        const int rc = launch_head_bwd_w(dlogits, pooled, n, in, classes, dW, db, stream);
+        if (rc != COMBAT_OK) return rc;
     }
     return COMBAT_OK;
 }
@@ -301,8 +331,5 @@ extern "C" int combat_head_bwd_weights(const float *dlogits, const float *pooled
     if (!dlogits || !pooled || !dW || !db || n <= 0 || hw < 4 || (hw & 3) || C <= 0 || classes <= 0 || classes > kMaxClasses)
         return COMBAT_EINVAL;
     const int in = C * (hw / 4) * (hw / 4);
-    COMBAT_LAUNCH(head_bwd_w_kernel, dim3((in + 255) / 256, classes, 8), dim3(256), 0, as_stream(stream), dlogits, pooled, n, in,
-                       classes, dW, db);
-    CB_LAUNCH_CHECK();
-    return COMBAT_OK;
+    return launch_head_bwd_w(dlogits, pooled, n, in, classes, dW, db, stream);
 }

@@ -292,38 +292,64 @@ __device__ __forceinline__ void crop_scatter(float *plane, int hw, const AugGeom
     atomicAdd(plane + sy * hw + sx, val);  // LDS atomic (global in the big-image variant)
 }
 
-__global__ __launch_bounds__(256) void augment_bwd_kernel(const __bf16 *__restrict__ d_c8, int cch,
-                                                          const float *__restrict__ params, int hw,
-                                                          float *__restrict__ d_x, int accumulate) {
+// The adjoint as a GATHER: no atomics, a fixed summation order (the scatter form -- every output pixel adding its four
+// weighted shares to an LDS image with ds_add_f32 -- cost the same 15 us and summed in whatever order the waves ran:
+// the generator's gradient differed in the last bits from run to run).  The gradient image is
+// staged in LDS; every source pixel (X, Y) -- crop-space pixel (u, v) = (X - ox, Y - oy) -- visits the output pixels
+// whose bilinear footprint can contain (u, v): the rotation maps output pixel o to s = R (o - c) + c and (u, v) is one
+// of its four taps iff s lies in [u - 1, u + 1) x [v - 1, v + 1), so o lies within (|cos| + |sin|) <= 1.415 of
+// q = R^T ((u, v) - c) + c in either axis: the 6 x 6 window [floor(q) - 2, floor(q) + 3] holds them all with 0.58
+// pixels to spare.  Each candidate recomputes s, the tap corner and the weights with the forward kernel's own
+// expressions (the same products the scatter adds), and the matches are summed in window order.
+__global__ __launch_bounds__(256) void augment_bwd_gather_kernel(const __bf16 *__restrict__ d_c8, int cch,
+                                                                 const float *__restrict__ params, int hw,
+                                                                 float *__restrict__ d_x, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int hw2 = hw * hw, tid = threadIdx.x, img = blockIdx.x;
-    for (int o = tid; o < 3 * hw2; o += 256) sm[o] = accumulate ? d_x[(long)img * 3 * hw2 + o] : 0.f;
+    for (int o = tid; o < hw2; o += 256) {
+        const __bf16 *gp = d_c8 + ((long)img * hw2 + o) * cch;
+        sm[o] = (float)gp[0], sm[hw2 + o] = (float)gp[1], sm[2 * hw2 + o] = (float)gp[2];
+    }
     __syncthreads();
     const AugGeom g = aug_geom(params, img, hw);
     for (int o = tid; o < hw2; o += 256) {
-        const int yo = o / hw, xo0 = o - yo * hw;
-        const int xo = g.flip ? hw - 1 - xo0 : xo0;
-        const __bf16 *gp = d_c8 + ((long)img * hw2 + o) * cch;
-        const float gv[3] = {(float)gp[0], (float)gp[1], (float)gp[2]};
-        if (g.rot) {
-            const float dx = xo - g.cx, dy = yo - g.cy;
-            const float sx = g.ca * dx - g.sa * dy + g.cx, sy = g.sa * dx + g.ca * dy + g.cy;
-            const float fx = floorf(sx), fy = floorf(sy);
-            const int x0 = (int)fx, y0 = (int)fy;
-            const float ax = sx - fx, ay = sy - fy;
-            for (int c = 0; c < 3; ++c) {
-                float *pl = sm + c * hw2;
-                crop_scatter(pl, hw, g, x0, y0, (1.f - ay) * (1.f - ax) * gv[c]);
-                crop_scatter(pl, hw, g, x0 + 1, y0, (1.f - ay) * ax * gv[c]);
-                crop_scatter(pl, hw, g, x0, y0 + 1, ay * (1.f - ax) * gv[c]);
-                crop_scatter(pl, hw, g, x0 + 1, y0 + 1, ay * ax * gv[c]);
+        const int Y = o / hw, X = o - Y * hw;
+        const int u = X - g.ox, v = Y - g.oy;
+        float acc[3] = {0.f, 0.f, 0.f};
+        if ((unsigned)u < (unsigned)hw && (unsigned)v < (unsigned)hw) {
+            if (g.rot) {
+                const float qx = g.ca * (u - g.cx) + g.sa * (v - g.cy) + g.cx, qy = -g.sa * (u - g.cx) + g.ca * (v - g.cy) + g.cy;
+                const int bx = (int)floorf(qx) - 2, by = (int)floorf(qy) - 2;
+                for (int jy = 0; jy < 6; ++jy) {
+                    const int yo = by + jy;
+                    if ((unsigned)yo >= (unsigned)hw) continue;
+                    for (int jx = 0; jx < 6; ++jx) {
+                        const int xo = bx + jx;
+                        if ((unsigned)xo >= (unsigned)hw) continue;
+                        const float dx = xo - g.cx, dy = yo - g.cy;
+                        const float sx = g.ca * dx - g.sa * dy + g.cx, sy = g.sa * dx + g.ca * dy + g.cy;
+                        const float fx = floorf(sx), fy = floorf(sy);
+                        const int x0 = (int)fx, y0 = (int)fy;
+                        if ((u != x0 && u != x0 + 1) || (v != y0 && v != y0 + 1)) continue;
+                        const float ax = sx - fx, ay = sy - fy;
+                        const float w = (v == y0 ? 1.f - ay : ay) * (u == x0 ? 1.f - ax : ax);
+                        const int m = yo * hw + (g.flip ? hw - 1 - xo : xo);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc[c] += w * sm[c * hw2 + m];
+                    }
+                }
+            } else {
+                const int m = v * hw + (g.flip ? hw - 1 - u : u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] = sm[c * hw2 + m];
             }
-        } else {
-            for (int c = 0; c < 3; ++c) crop_scatter(sm + c * hw2, hw, g, xo, yo, gv[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float *d = d_x + ((long)img * 3 + c) * hw2 + o;
+            *d = accumulate ? *d + acc[c] : acc[c];
         }
     }
-    __syncthreads();
-    for (int o = tid; o < 3 * hw2; o += 256) d_x[(long)img * 3 * hw2 + o] = sm[o];
 }
 
 // hw > 96: scatter with global fp32 atomics into d_x (zeroed by the launcher unless `accumulate`)
@@ -491,8 +517,8 @@ extern "C" int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const f
         return COMBAT_OK;
     }
     const int bytes = 3 * hw * hw * 4;
-    if (set_smem(augment_bwd_kernel, bytes)) return COMBAT_ELAUNCH;
-    COMBAT_LAUNCH(augment_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream),
+    if (set_smem(augment_bwd_gather_kernel, bytes)) return COMBAT_ELAUNCH;
+    COMBAT_LAUNCH(augment_bwd_gather_kernel, dim3(n), dim3(256), bytes, as_stream(stream),
                        reinterpret_cast<const __bf16 *>(d_c8), c8_channels, params, hw, d_x, accumulate);
     CB_LAUNCH_CHECK();
     return COMBAT_OK;

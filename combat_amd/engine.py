@@ -557,6 +557,19 @@ def rec_wgrad(plan: Plan, what: str, src, dy, pc: PackedConv, dw, pro: Optional[
         plan.pending_reduces.append((what + ".reduce", a, len(plan.calls) - 1))
 
 
+def set_deterministic(on: bool) -> None:
+    """Process-wide deterministic mode of the kernel library (include/combat_hip.h, combat_set_deterministic; default:
+    COMBAT_DETERMINISTIC=1 in the environment): every parameter-gradient reduction and the augmentation adjoint in
+    a fixed summation order, so two runs on the same inputs and draws give bit-identical parameters.  The launches
+    read the switch when they run, so recorded plans follow it; weight-gradient calls always carry the per-queue
+    workspace the ordered reductions need."""
+    lib.combat_set_deterministic(1 if on else 0)
+
+
+def deterministic() -> bool:
+    return bool(lib.combat_get_deterministic())
+
+
 _WGRAD_SLABS: Dict = {}
 
 

@@ -43,6 +43,22 @@ extern "C" {
 const char *combat_version(void);
 int combat_abi_version(void);
 
+/* Deterministic mode (process-wide; default: the COMBAT_DETERMINISTIC environment variable, "1" = on).
+ * The reference sets neither seeds nor cudnn flags (no manual_seed / cudnn.deterministic anywhere in it):
+ * on a GPU it runs with whatever order cuDNN's kernels sum in; on the CPU its modules are reproducible
+ * for a fixed thread count (tests/golden/make_golden.py relies on that).
+ * Off: partial sums over pixel ranges meet in the gradient buffers through a few fp32 atomics per
+ * element (weight gradients of the stride-2 / 1x1 / 8-channel kernels, the 3x3 slab reduction, the
+ * head's and the bias gradients) and the augmentation adjoint scatters with LDS atomics: results
+ * differ in the last bits from run to run.  On: every one of those reductions has a fixed summation
+ * order (slabs + an ordered reduction launch; one sample range; a gathering adjoint) -- two runs on
+ * the same inputs give bit-identical parameters; costs a few launches per backward pass (DESIGN
+ * section 5).  Weight-gradient launches then REQUIRE the workspace combat_conv_wgrad_workspace_bytes
+ * asks for (COMBAT_EINVAL without it).  Not covered: combat_warp_bwd, combat_augment_bwd on images
+ * wider than 96 pixels (global scatter), the logged loss sums. */
+void combat_set_deterministic(int on);
+int combat_get_deterministic(void);
+
 /* ------------------------------------------------------------------------------------------
  * Convolution as gather-GEMM on MFMA (v_mfma_f32_16x16x32_bf16), fused prologue/epilogue.
  *

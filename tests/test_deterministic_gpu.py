@@ -1,0 +1,170 @@
+"""Deterministic mode of the kernel library (combat_set_deterministic / COMBAT_DETERMINISTIC=1, include/combat_hip.h):
+every reduction that ends in a parameter gradient -- and the augmentation adjoint on the way to the generator's -- has
+a fixed summation order, so two runs give the same BITS; the default forms meet in the gradient buffers through fp32
+atomics and differ in the last place from run to run ("run-to-run nondeterminism").  Each case checks
+(a) two launches in deterministic mode are bit-identical, (b) they agree with the default form to rounding, and the
+step-level case that two fresh step objects fed the same batches and draws end with bit-identical parameters."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_kernels_gpu import bf16, dev, g, make_conv, nhwc, rb, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def ops():
+    from combat_amd import ops as O
+    return O
+
+
+@pytest.fixture
+def det():
+    from combat_amd import engine
+    engine.set_deterministic(True)
+    assert engine.deterministic()
+    yield
+    engine.set_deterministic(False)
+
+
+WG_SHAPES = [  # n, hw, c, k, r, stride, pad: stride-2 3x3, 1x1 shortcut, 8-channel input (all-taps kernel), 3-channel output,
+    (128, 16, 128, 256, 3, 2, 1), (128, 16, 128, 256, 1, 2, 0), (128, 32, 3, 64, 3, 1, 1), (64, 32, 64, 3, 3, 1, 1),
+    (128, 8, 256, 256, 3, 1, 1), (32, 32, 64, 64, 3, 1, 1), (3, 6, 128, 256, 3, 2, 1)]   # DMA-staged 3x3 (slab reduction); a tiny one
+
+
+def _wgrad_case(ops, n, hw, c, k, r, stride, pad):
+    c_pad = 8 if c == 3 else c
+    x = torch.randn(n, c, hw, hw, generator=g(20))
+    w, pc = make_conv(ops, k, c, r, stride, pad, 21, c_pad=c_pad, dup=(c == 3))
+    p, q = pc.out_hw(hw, hw)
+    dy = torch.randn(n, k, p, q, generator=g(22))
+    dy_d = torch.zeros(n, p, q, pc.Kc, dtype=bf16, device="cuda")
+    dy_d[..., :k] = nhwc(dy)
+    if c == 3:
+        xin = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+        ops.image_to_c8(dev(rb(x)), xin)
+    else:
+        xin = nhwc(x)
+    return xin, dy_d, pc, (k, r * r, c)
+
+
+@pytest.mark.parametrize("n,hw,c,k,r,stride,pad", WG_SHAPES)
+def test_weight_gradients_have_a_fixed_order(ops, det, n, hw, c, k, r, stride, pad):
+    from combat_amd import engine
+    xin, dy_d, pc, shape = _wgrad_case(ops, n, hw, c, k, r, stride, pad)
+    outs = []
+    for _ in range(3):
+        dw = torch.zeros(*shape, device="cuda")
+        ops.conv_wgrad(xin, dy_d, pc, dw, workspace=True)
+        outs.append(dw)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    engine.set_deterministic(False)
+    dw0 = torch.zeros(*shape, device="cuda")
+    ops.conv_wgrad(xin, dy_d, pc, dw0, workspace=True)
+    assert rel_l2(outs[0], dw0) < 2e-6
+    # accumulation into a non-zero buffer: dw += (ordered sum), as every backward pass after the first relies on
+    engine.set_deterministic(True)
+    acc = outs[0].clone()
+    ops.conv_wgrad(xin, dy_d, pc, acc, workspace=True)
+    assert rel_l2(acc, 2 * dw0) < 2e-6
+
+
+def test_ordered_weight_gradient_needs_its_workspace(ops, det):
+    """Several pixel ranges and no room for their slabs: the deterministic form refuses instead of falling back to atomics."""
+    xin, dy_d, pc, shape = _wgrad_case(ops, 128, 16, 128, 256, 3, 2, 1)
+    dw = torch.zeros(*shape, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.conv_wgrad(xin, dy_d, pc, dw, workspace=None)
+
+
+def test_head_and_bias_gradients_have_a_fixed_order(ops):
+    """combat_head_bwd_weights and combat_colsum are two-stage ordered reductions in EVERY mode (sample / row ranges meet
+    in a second launch, through scratch the library owns per stream): the same bits twice, with the switch off."""
+    from combat_amd._lib import lib
+    assert not lib.combat_get_deterministic()
+    n, hw, c, classes = 128, 4, 512, 10
+    st = torch.cuda.current_stream().cuda_stream
+    dl = torch.randn(n, classes, generator=g(1)).cuda()
+    pooled = torch.randn(n, c, generator=g(2)).cuda()
+
+    def head(init):
+        dw, db = torch.full((classes, c), init, device="cuda"), torch.full((classes,), init, device="cuda")
+        ops.check(lib.combat_head_bwd_weights(dl.data_ptr(), pooled.data_ptr(), n, hw, c, classes, dw.data_ptr(), db.data_ptr(), st), "head w")
+        return dw, db
+    a, b = head(0.0), head(0.0)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert rel_l2(a[0], dl.t() @ pooled) < 1e-5 and rel_l2(a[1], dl.sum(0)) < 1e-5
+    a1 = head(1.0)                                   # accumulates into what is there
+    assert rel_l2(a1[0] - 1.0, a[0]) < 1e-5 and rel_l2(a1[1] - 1.0, a[1]) < 1e-5
+    for rows, C, c_out in ((128 * 32 * 32, 64, 64), (128 * 32 * 32, 8, 3), (1000, 16, 16)):
+        x = torch.randn(rows, C, generator=g(3)).to(bf16).cuda()
+        outs = []
+        for _ in range(2):
+            out = torch.full((c_out,), 7.0, device="cuda")      # (overwritten, not accumulated into)
+            ops.colsum(x, c_out, out)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        assert rel_l2(outs[0], x.float().sum(0)[:c_out]) < 1e-4
+
+
+def test_gathering_augmentation_adjoint(ops):
+    """combat_augment_bwd gathers (no LDS atomics) in every mode: the oracle's values (test_kernels_gpu) and the same bits twice."""
+    n, hw = 128, 32
+    rng = np.random.default_rng(5)
+    par = np.stack([rng.integers(-5, 6, n), rng.integers(-5, 6, n), np.radians(rng.uniform(-10, 10, n)) * (rng.random(n) < 0.5),
+                    rng.integers(0, 2, n)], 1).astype(np.float32)
+    d8 = torch.zeros(n, hw, hw, 8, dtype=bf16, device="cuda")
+    d8[..., :3] = torch.randn(n, hw, hw, 3, generator=g(7)).to(bf16).cuda()
+    outs = []
+    for _ in range(2):
+        dx = torch.empty(n, 3, hw, hw, device="cuda")
+        ops.augment_bwd(d8, n, hw, dx, dev(torch.tensor(par)))
+        outs.append(dx)
+    assert torch.equal(outs[0], outs[1])
+    # adjoint identity against the forward kernel: <A x, d> == <x, A^T d>
+    x = torch.randn(n, 3, hw, hw, generator=g(8)).cuda()
+    out8 = torch.empty(n, hw, hw, 8, dtype=bf16, device="cuda")
+    outf = torch.empty(n, 3, hw, hw, device="cuda")
+    ops.augment_fwd(x, n, hw, out8, dev(torch.tensor(par)), None, outf)
+    d = d8[..., :3].float().permute(0, 3, 1, 2)
+    lhs, rhs = float((outf.double() * d.double()).sum()), float((x.double() * outs[0].double()).sum())
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))
+
+
+def _run_steps(steps=3):
+    import bench
+    from combat_amd import step as step_mod
+    device = torch.device("cuda", 0)
+    opt = bench.Opt()
+    import random
+    random.seed(0)          # the step consumes three RNG streams where the reference does (step.draw_randomness)
+    np.random.seed(0)
+    torch.manual_seed(100)
+    nets = bench.build_nets(device)
+    batches = bench.synth_batches(4, opt.bs, 0, device)
+    st = step_mod.AlternatedStep(*nets, opt)
+    for i in range(steps):
+        st.run(*batches[i % 4])
+    torch.cuda.synchronize()
+    m = st.read_metrics()
+    state = [t.detach().clone() for mod in nets[:2] for t in list(mod.parameters()) + list(mod.buffers())]   # (parameters alias the engines' flat buffers)
+    return state, m
+
+
+def test_two_runs_of_the_alternated_step_give_the_same_bits(det):
+    """Three steps at the benchmarked batch from identical initial state, batches and draws, twice: every parameter of
+    the surrogate and of the generator bit-identical, every integer counter equal (the logged loss sums are float
+    atomics over images and are compared to rounding)."""
+    pa, ma = _run_steps()
+    pb, mb = _run_steps()
+    assert len(pa) == len(pb) and len(pa) > 60
+    for u, v in zip(pa, pb):
+        assert torch.equal(u, v)
+    for k in ma:
+        if "correct" in k or k in ("samples", "clean_model_bd_ba", "clean_model_bd_asr"):
+            assert ma[k] == mb[k], k
+        else:
+            assert abs(ma[k] - mb[k]) <= 1e-5 * max(1.0, abs(ma[k])), k
