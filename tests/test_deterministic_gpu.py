@@ -168,3 +168,35 @@ def test_two_runs_of_the_alternated_step_give_the_same_bits(det):
             assert ma[k] == mb[k], k
         else:
             assert abs(ma[k] - mb[k]) <= 1e-5 * max(1.0, abs(ma[k])), k
+
+
+def _run_victim_steps(steps=3):
+    import random
+
+    import bench
+    from combat_amd import step as step_mod
+    device = torch.device("cuda", 0)
+    opt = bench.Opt()
+    random.seed(0)
+    np.random.seed(0)
+    torch.manual_seed(100)
+    netc, netg, _, _ = bench.build_nets(device)
+    batches = bench.synth_batches(4, opt.bs, 0, device)
+    st = step_mod.ClassifierStep(netc, opt, netg.eval())
+    for i in range(steps):
+        x, t = batches[i % 4]
+        poisoned = (t.cpu() == 0) & (torch.rand(t.shape[0], generator=torch.Generator().manual_seed(i)) < 0.5)
+        st.run(x, t, poisoned)
+    torch.cuda.synchronize()
+    return [v.detach().clone() for v in list(netc.parameters()) + list(netc.buffers())], st.read_metrics()
+
+
+def test_two_runs_of_the_victim_step_give_the_same_bits(det):
+    """train_victim.py's step (ClassifierStep with the UNet trigger: generator forward, trigger, augmentation, surrogate
+    forward / backward / SGD) three times at B = 128, twice: bit-identical classifier state."""
+    pa, ma = _run_victim_steps()
+    pb, mb = _run_victim_steps()
+    assert len(pa) == len(pb) and len(pa) > 60
+    for u, v in zip(pa, pb):
+        assert torch.equal(u, v)
+    assert ma["correct"] == mb["correct"] and abs(ma["loss_sum"] - mb["loss_sum"]) <= 1e-5 * max(1.0, abs(ma["loss_sum"]))
