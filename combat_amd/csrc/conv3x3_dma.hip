@@ -1082,7 +1082,9 @@ int launch_hb(const DmaParams &p, hipStream_t st) {
     using G = DGeo<TW, NW, RPW>;
     constexpr int stage = HB * G::HBYTES + 3 * BN * 128 + 1024;   // (+ the weight prefetch's scratch KB)
     constexpr int ep = EpiCfg<TileCfg<128, BN, 4>>::LDS_BYTES / 4 * NW;
-    constexpr int smem = stage > ep ? stage : ep;
+    constexpr int smem0 = stage > ep ? stage : ep;
+    static const int exp_pad = getenv("COMBAT_EXP_LDS") ? atoi(getenv("COMBAT_EXP_LDS")) : 0;   // EXPERIMENT: force a footprint
+    const int smem = exp_pad > smem0 && (BN == 32 || getenv("COMBAT_EXP_LDS_ALL")) ? exp_pad : smem0;
     auto kern = conv3x3_dma_kernel<BN, TW, HB, NW, RPW>;
     static bool attr_set = false;
     if (!attr_set) {
