@@ -676,7 +676,7 @@ bool fill_reduce_first(const combat_wgrad_args *prev, W3dParams &p) {
     p.red_base = p.red_tiles_c = p.red_split = p.red_k_real = p.red_c_real = p.red_pad = 0;
     if (!prev) return true;
     W3dParams q;
-    if (!w3d_plan(prev, q)) return false;
+    if (!w3d_plan(prev, q)) return true;     // (not a launch of this kernel: the generic kernels reduce their own slabs)
     if (!q.ws) return true;                  // (that launch needed no reduction)
     p.red_ws = q.ws;
     p.red_dw = prev->dw;
