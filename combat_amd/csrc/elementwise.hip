@@ -443,7 +443,7 @@ inline unsigned grid_for(long total, int cap = 4096) {
 __global__ __launch_bounds__(256) void log_terms_kernel(const float *__restrict__ x, const float *__restrict__ xb,
                                                         const float *__restrict__ mse_partial, int n_partial, int n, int hw,
                                                         const float *__restrict__ logits, int n_logits,
-                                                        double *__restrict__ acc, double *__restrict__ hits) {
+                                                        double *__restrict__ acc, double *__restrict__ hits, double *__restrict__ part) {
     __shared__ float red[2][256];
     const int tid = threadIdx.x, plane = blockIdx.x;
     const float *px = x + (long)plane * hw * hw, *pb = xb + (long)plane * hw * hw;
@@ -475,7 +475,9 @@ __global__ __launch_bounds__(256) void log_terms_kernel(const float *__restrict_
     }
     if (tid == 0) {
         const double planes = (double)n * 3.0;
-        atomicAdd(acc + 1, (double)red[0][0] / (planes * (PH - 1) * PW) + (double)red[1][0] / (planes * PH * (PW - 1)));
+        const double v = (double)red[0][0] / (planes * (PH - 1) * PW) + (double)red[1][0] / (planes * PH * (PW - 1));
+        if (part) part[plane] = v;      // deterministic mode: log_terms_finish_kernel adds the planes in order
+        else atomicAdd(acc + 1, v);
     }
     if (plane == 0) {
         if (mse_partial) {
@@ -503,6 +505,12 @@ __global__ __launch_bounds__(256) void log_terms_kernel(const float *__restrict_
             if (tid == 0) atomicAdd(hits, (double)rh[0]);
         }
     }
+}
+
+__global__ void log_terms_finish_kernel(const double *__restrict__ part, int planes, double *__restrict__ acc) {
+    double s = 0.0;
+    for (int i = 0; i < planes; ++i) s += part[i];
+    acc[1] += s;
 }
 
 }  // namespace
@@ -643,9 +651,14 @@ extern "C" int combat_log_terms(const float *x, const float *xb, const float *ms
                                 const float *detector_logits, double *acc2, double *hits, void *stream) {
     COMBAT_PLAN_HOOK(combat_log_terms, x, xb, mse_partial, n, hw, detector_logits, acc2, hits);
     if (!x || !xb || !acc2 || n <= 0 || hw < 2) return COMBAT_EINVAL;
+    double *part = combat_deterministic() ? reinterpret_cast<double *>(combat_stream_scratch(stream, (size_t)3 * n * sizeof(double))) : nullptr;
     COMBAT_LAUNCH(log_terms_kernel, dim3(3 * n), dim3(256), 0, as_stream(stream), x, xb, mse_partial, 3 * n, n, hw,
-                       detector_logits, n, acc2, hits);
+                       detector_logits, n, acc2, hits, part);
     CB_LAUNCH_CHECK();
+    if (part) {
+        COMBAT_LAUNCH(log_terms_finish_kernel, dim3(1), dim3(1), 0, as_stream(stream), (const double *)part, 3 * n, acc2);
+        CB_LAUNCH_CHECK();
+    }
     return COMBAT_OK;
 }
 

@@ -20,6 +20,7 @@ struct HeadFwdArgs {
     int n;
     float *pooled, *logits, *loss_sum;
     int *correct, *correct2;
+    float *loss_part;   // deterministic mode: image i's share of the loss goes to loss_part[i]; head_loss_finish_kernel adds them in order
 };
 
 __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const HeadFwdArgs a) {
             for (int j = 0; j < a.classes; ++j) se += expf(lg[j] - mx);
             const int t = (int)a.targets[img];
             const float li = logf(se) + mx - lg[t];
-            if (a.loss_sum) atomicAdd(a.loss_sum, a.loss_weight * li / (float)a.n);
+            if (a.loss_part) a.loss_part[img] = a.loss_weight * li / (float)a.n;
+            else if (a.loss_sum) atomicAdd(a.loss_sum, a.loss_weight * li / (float)a.n);
             if (a.correct && am == t) atomicAdd(a.correct, 1);
         }
         if (a.targets2 && a.correct2 && am == (int)a.targets2[img]) atomicAdd(a.correct2, 1);
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(256) void head_fwd_bwd_kernel(const HeadFwdArgs a, 
         for (int j = 0; j < a.classes; ++j) se += expf(lg[j] - mx);
         const int t = (int)a.targets[img];
         const float li = logf(se) + mx - lg[t];
-        if (a.loss_sum) atomicAdd(a.loss_sum, a.loss_weight * li / (float)a.n);
+        if (a.loss_part) a.loss_part[img] = a.loss_weight * li / (float)a.n;
+        else if (a.loss_sum) atomicAdd(a.loss_sum, a.loss_weight * li / (float)a.n);
         if (a.correct && am == t) atomicAdd(a.correct, 1);
         if (a.targets2 && a.correct2 && am == (int)a.targets2[img]) atomicAdd(a.correct2, 1);
         for (int j = 0; j < a.classes; ++j) {       // (head_bwd_feat_kernel's expression, from the same logits)
@@ -230,6 +233,19 @@ __global__ __launch_bounds__(256) void head_bwd_w_finish_kernel(const float *__r
     else db[e - (long)classes * in] += s;
 }
 
+// deterministic mode: the running loss sum takes the images' shares in image order (they used to arrive as n float atomics)
+__global__ void head_loss_finish_kernel(const float *__restrict__ part, int n, float *__restrict__ loss_sum) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += part[i];
+    *loss_sum += s;
+}
+
+// scratch for the per-image loss shares (deterministic mode with a loss accumulator and labels), or nullptr
+float *head_loss_part(const float *loss_sum, const int64_t *targets, int n, void *stream) {
+    if (!loss_sum || !targets || !combat_deterministic()) return nullptr;
+    return combat_stream_scratch(stream, (size_t)n * sizeof(float));
+}
+
 int launch_head_bwd_w(const float *dlogits, const float *pooled, int n, int in, int classes, float *dW, float *db, void *stream) {
     constexpr int kRanges = 8;
     float *part = combat_stream_scratch(stream, (size_t)kRanges * ((size_t)classes * in + classes) * sizeof(float));
@@ -259,7 +275,7 @@ extern "C" int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t 
     const int bytes = in * 4;
     if (bytes > 150 * 1024) return COMBAT_EINVAL;
     HeadFwdArgs a{reinterpret_cast<const __bf16 *>(feat), hw, C, classes, W, b, targets, targets2, loss_weight, n,
-                  pooled, logits, loss_sum, correct, correct2};
+                  pooled, logits, loss_sum, correct, correct2, head_loss_part(loss_sum, targets, n, stream)};
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_fwd_kernel),
@@ -269,6 +285,10 @@ extern "C" int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t 
     }
     COMBAT_LAUNCH(head_fwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), a);
     CB_LAUNCH_CHECK();
+    if (a.loss_part) {
+        COMBAT_LAUNCH(head_loss_finish_kernel, dim3(1), dim3(1), 0, as_stream(stream), (const float *)a.loss_part, n, loss_sum);
+        CB_LAUNCH_CHECK();
+    }
     return COMBAT_OK;
 }
 
@@ -312,7 +332,7 @@ extern "C" int combat_head_fwd_bwd(const void *feat, int32_t n, int32_t hw, int3
     const int bytes = in * 4;
     if (bytes > 150 * 1024) return COMBAT_EINVAL;
     HeadFwdArgs a{reinterpret_cast<const __bf16 *>(feat), hw, C, classes, W, b, targets, targets2, loss_weight, n,
-                  pooled, logits, loss_sum, correct, correct2};
+                  pooled, logits, loss_sum, correct, correct2, head_loss_part(loss_sum, targets, n, stream)};
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(head_fwd_bwd_kernel),
@@ -322,6 +342,10 @@ extern "C" int combat_head_fwd_bwd(const void *feat, int32_t n, int32_t hw, int3
     }
     COMBAT_LAUNCH(head_fwd_bwd_kernel, dim3(n), dim3(256), bytes, as_stream(stream), a, dlogits, reinterpret_cast<__bf16 *>(d_feat));
     CB_LAUNCH_CHECK();
+    if (a.loss_part) {
+        COMBAT_LAUNCH(head_loss_finish_kernel, dim3(1), dim3(1), 0, as_stream(stream), (const float *)a.loss_part, n, loss_sum);
+        CB_LAUNCH_CHECK();
+    }
     return COMBAT_OK;
 }
 

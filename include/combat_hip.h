@@ -54,8 +54,10 @@ int combat_abi_version(void);
  * order (slabs + an ordered reduction launch; one sample range; a gathering adjoint) -- two runs on
  * the same inputs give bit-identical parameters; costs a few launches per backward pass (DESIGN
  * section 5).  Weight-gradient launches then REQUIRE the workspace combat_conv_wgrad_workspace_bytes
- * asks for (COMBAT_EINVAL without it).  Not covered: combat_warp_bwd, combat_augment_bwd on images
- * wider than 96 pixels (global scatter), the logged loss sums. */
+ * asks for (COMBAT_EINVAL without it).  The logged sums follow: the images' loss shares
+ * (combat_head_fwd*) and the planes' gradient-L2 terms (combat_log_terms) are added in index order by a
+ * one-thread launch, so every metric is reproducible too.  Not covered: combat_warp_bwd,
+ * combat_augment_bwd on images wider than 96 pixels (global scatter). */
 void combat_set_deterministic(int on);
 int combat_get_deterministic(void);
 
