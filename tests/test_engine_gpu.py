@@ -691,7 +691,15 @@ def _ema(v, a=0.1):
 
 @pytest.mark.parametrize("name,steps", [("trajectory_lr2e3", 100), ("trajectory", 40), ("trajectory_celeba", 40)])
 def test_trajectory_vs_reference_trace(mods, golden, name, steps):
-    """SURVEY 8(d) / north_star "loss curves must match": alternated steps at B = 32 over a pool of 25 fixed
+    trajectory_check(mods, golden, name, steps)
+
+
+def trajectory_check(mods, golden, name, steps, pinned=None):
+    """(pinned: tests/test_deterministic_gpu.py -- in deterministic mode a run is reproducible, so the bounds can sit just
+    above what THE run measures instead of covering the run-to-run spread: dict(ema={loss: relative bound}, counter=max
+    per-step deviation in images, total=relative bound on the counters' sums).)
+
+    SURVEY 8(d) / north_star "loss curves must match": alternated steps at B = 32 over a pool of 25 fixed
     synthetic batches (augmentation off, recorded num_bd / sigma per step) against the trace the REFERENCE's
     own modules + torch.optim.SGD produced in fp32 (tests/golden/make_golden.py::golden_trajectory*).
 
@@ -753,7 +761,9 @@ def test_trajectory_vs_reference_trace(mods, golden, name, steps):
         worst = int(np.argmax(dev / np.maximum(np.abs(e_r), 1e-9)))
         report[k] = (float((dev / np.maximum(np.abs(e_r), 1e-9)).max()), worst)
         tol = np.full(steps, rel)
-        if k == "loss_ce" and tight:
+        if pinned is not None:
+            tol[:] = pinned["ema"][k]
+        elif k == "loss_ce" and tight:
             tol[60:] = 0.10      # past step 60 loss_ce alternates 0 <-> 2 with the step's blur sigma and small
             #                      differences are amplified: the CPU bf16 emulation itself is 7 % off fp32 at step 99,
             #                      HIP runs measured 3-6 % (they differ run to run: fp32 atomics reorder sums)
@@ -768,10 +778,14 @@ def test_trajectory_vs_reference_trace(mods, golden, name, steps):
         # (past step 60 bd_correct follows the spiky loss_ce, see above)
         d = np.abs(o - r)
         near, far = max(2, b // 8), max(4, 10 * b // 32)       # 4 and 10 images at B = 32
+        if pinned is not None:
+            far = pinned["counter"]
+        print("%s %-20s max |ours - reference| %2d (step %d), first 60 steps: %.1f %% within %d, totals %d vs %d" % (
+            name, k, int(d.max()), int(d.argmax()), 100.0 * (d[: min(60, steps)] <= near).mean(), near, int(o.sum()), int(r.sum())))
         assert np.all(d <= far), (name, k, int(d.argmax()), d.max())
         head = d[: min(60, steps)]
         assert (head <= near).mean() >= 0.95, (name, k, np.nonzero(head > near)[0].tolist(), head.max())
-        assert abs(o.sum() - r.sum()) <= max(0.015 * steps * b, 8), (name, k, o.sum(), r.sum())
+        assert abs(o.sum() - r.sum()) <= (pinned["total"] * steps * b if pinned is not None else max(0.015 * steps * b, 8)), (name, k, o.sum(), r.sum())
 
 
 @pytest.mark.parametrize("b", [8, 128])
