@@ -422,8 +422,10 @@ int combat_augment_bwd(const void *d_c8, int32_t c8_channels, const float *param
  * correct2 += #argmax==targets2 (both optional; classes <= 16).
  * Backward: dlogits fp32 [n][classes] = loss_weight/n * (softmax - onehot);
  * d_feat bf16 [n][hw][hw][C] = dlogits W / 16 (may be NULL); and (if dW != NULL)
- * dW fp32 [classes][in] += dlogits^T pooled, db fp32 [classes] += column sums (accumulated with fp32
- * atomics over sample ranges, like the convolution weight gradients: zero them first).
+ * dW fp32 [classes][in] += dlogits^T pooled, db fp32 [classes] += column sums (accumulated INTO the
+ * buffers: zero them first).  Eight sample ranges are summed first and a second launch adds them in
+ * order (no atomics: the same bits every run); their partial sums live in scratch the library owns --
+ * 2 MB per stream, hipMalloc'ed at the stream's first such call and kept (combat_colsum uses it too).
  * ------------------------------------------------------------------------------------------ */
 int combat_head_fwd(const void *feat, int32_t n, int32_t hw, int32_t C, const float *W, const float *b,
                     int32_t classes, const int64_t *targets, float loss_weight, float *pooled, float *logits,
@@ -474,7 +476,8 @@ int combat_memset_zero(void *ptr, int64_t bytes, void *stream);
  * and re-packed bias at a step boundary (train_generator.py:169-171: inputs.to(device) and the per-step draws). */
 int combat_copy3(void *dst0, const void *src0, int64_t bytes0, void *dst1, const void *src1, int64_t bytes1,
                  void *dst2, const void *src2, int64_t bytes2, void *stream);
-/* column sums of a bf16 [rows][C] tensor into fp32 out[c_out] (overwritten): conv bias gradient */
+/* column sums of a bf16 [rows][C] tensor into fp32 out[c_out] (overwritten): conv bias gradient.  Two launches: row
+ * groups, then their sums in a fixed order (library-owned per-stream scratch, see combat_head_bwd). */
 int combat_colsum(const void *x, int64_t rows, int32_t C, int32_t c_out, float *out, void *stream);
 /* The logged-only terms of one step in one launch (train_generator.py:234-247): acc2[0] += MSE(inputs_bd, inputs) from the
  * trigger kernel's per-plane partial sums (mse_partial [3n], may be NULL), acc2[1] += loss_grad_l2 = MSE of the H- and
